@@ -27,3 +27,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def zpq():
+    """The product package (zpaq-v_amd/) loaded as module zpaq_v_amd."""
+    import __graft_entry__ as ge
+    return ge.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(zpq):
+    ctx = zpq.Context(0)
+    yield ctx
+    ctx.close()

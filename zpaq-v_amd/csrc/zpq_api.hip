@@ -1,0 +1,452 @@
+// zpq_api.hip -- the GPU half of the C ABI in include/zpaq_hip.h: per-device
+// context, state-slot management, kernel selection and launch.
+//
+// Data layout in HBM (DESIGN.md has the full picture):
+//   * read-only tables (squash/stretch/dt/dt2k/ns, ~80 KiB) uploaded once per ctx;
+//   * one DModel + init image per (ctx, model);
+//   * a pool of per-block STATE SLOTS, each DModel::slot_bytes (12.07 MiB at level 2):
+//     [VM regs | R[256] | MATCH scalars | H | M | per-component cm/ht/a16 tables].
+//     A slot is owned by one resident workgroup (generic kernel) or one lane group
+//     (chain kernel) and re-initialised in-kernel between blocks;
+//   * caller-provided in/out slabs addressed by in_off/out_off.
+// There is no CPU fallback anywhere in this file: if HIP is unusable every
+// compute entry point returns ZPQ_E_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/zpaq_hip.h"
+#include "zpq_common.h"
+#include "zpq_host.h"
+
+extern "C" void zpq_launch_generic(const DBatch *B, int decode, int grid, hipStream_t stream);
+extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
+extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
+extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, hipStream_t stream);
+extern "C" const char *zpq_chain_kernel_name(const DModel *M, int decode);
+
+#define HIPCK(x)                                                              \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (e_ != hipSuccess) {                                               \
+            fprintf(stderr, "[zpaq_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? ZPQ_E_NOMEM : ZPQ_E_NODEVICE; \
+        }                                                                     \
+    } while (0)
+
+struct DevModel {
+    DModel *d_model = nullptr;
+    uint32_t *d_img = nullptr;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return ZPQ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 8 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ZPQ_E_NOMEM; }
+        cap = want;
+        return ZPQ_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct zpq_ctx {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int16_t *d_squash = nullptr, *d_stretch = nullptr, *d_dt2k = nullptr;
+    uint32_t *d_dt = nullptr, *d_stretch_c = nullptr;
+    uint8_t *d_ns = nullptr;
+    std::map<uint64_t, DevModel> models;
+    DevBuf slots;
+    uint64_t budget = 0;
+    int last_slots = 0;
+    const char *last_name = "";
+    // staging for the host-pointer entry points
+    DevBuf s_in, s_out, s_inoff, s_outoff, s_u32[4], s_status, s_misc;
+    std::mutex mu;
+};
+
+struct zpq_block {
+    zpq_ctx *ctx;
+    const zpq_model *model;
+    uint8_t *slot;
+    bool fresh;
+};
+
+// ------------------------------------------------------------------ ctx
+extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
+{
+    if (!out) return ZPQ_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZPQ_E_NODEVICE;
+    if (device < 0 || device >= ndev) return ZPQ_E_ARG;
+    int tst = ZPQ_OK;
+    const zpq::Tables &T = zpq::tables(&tst);
+    if (tst != ZPQ_OK) return tst;
+    HIPCK(hipSetDevice(device));
+    zpq_ctx *c = new (std::nothrow) zpq_ctx();
+    if (!c) return ZPQ_E_NOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount;
+    HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCK(hipEventCreate(&c->ev0));
+    HIPCK(hipEventCreate(&c->ev1));
+    // device tables: squash/stretch/dt2k narrowed to i16 (all values fit)
+    std::vector<int16_t> sq(4096), st(32768), d2(256);
+    for (int i = 0; i < 4096; i++) sq[i] = (int16_t)T.squash[i];
+    for (int i = 0; i < 32768; i++) st[i] = (int16_t)T.stretch[i];
+    for (int i = 0; i < 256; i++) d2[i] = (int16_t)T.dt2k[i];
+    HIPCK(hipMalloc((void **)&c->d_squash, 4096 * 2));
+    HIPCK(hipMalloc((void **)&c->d_stretch, 32768 * 2));
+    HIPCK(hipMalloc((void **)&c->d_dt2k, 256 * 2));
+    HIPCK(hipMalloc((void **)&c->d_dt, 1024 * 4));
+    HIPCK(hipMalloc((void **)&c->d_ns, 1024));
+    HIPCK(hipMalloc((void **)&c->d_stretch_c, sizeof T.stretch_c));
+    HIPCK(hipMemcpy(c->d_squash, sq.data(), 4096 * 2, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_stretch, st.data(), 32768 * 2, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_dt2k, d2.data(), 256 * 2, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_dt, T.dt, 1024 * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_ns, T.ns, 1024, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_stretch_c, T.stretch_c, sizeof T.stretch_c, hipMemcpyHostToDevice));
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->budget = (uint64_t)fr / 4 * 3;
+    else c->budget = 64ull << 30;
+    *out = c;
+    return ZPQ_OK;
+}
+
+extern "C" void zpq_ctx_destroy(zpq_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->models) { (void)hipFree(kv.second.d_model); (void)hipFree(kv.second.d_img); }
+    c->slots.release();
+    c->s_in.release(); c->s_out.release(); c->s_inoff.release(); c->s_outoff.release();
+    for (auto &b : c->s_u32) b.release();
+    c->s_status.release(); c->s_misc.release();
+    (void)hipFree(c->d_squash); (void)hipFree(c->d_stretch); (void)hipFree(c->d_dt2k);
+    (void)hipFree(c->d_dt); (void)hipFree(c->d_ns); (void)hipFree(c->d_stretch_c);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int zpq_ctx_sync(zpq_ctx *c)
+{
+    if (!c) return ZPQ_E_ARG;
+    HIPCK(hipStreamSynchronize(c->stream));
+    return ZPQ_OK;
+}
+extern "C" void *zpq_ctx_stream(zpq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes)
+{
+    if (!c) return ZPQ_E_ARG;
+    c->budget = bytes;
+    return ZPQ_OK;
+}
+extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return c ? c->last_slots : 0; }
+extern "C" const char *zpq_ctx_last_kernel_name(const zpq_ctx *c) { return c ? c->last_name : ""; }
+extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
+{
+    if (!c || !c->ev_valid) return -1.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+static int get_dev_model(zpq_ctx *c, const zpq_model *m, DevModel *out)
+{
+    auto it = c->models.find(m->id);
+    if (it != c->models.end()) { *out = it->second; return ZPQ_OK; }
+    DevModel dm;
+    HIPCK(hipMalloc((void **)&dm.d_model, sizeof(DModel)));
+    HIPCK(hipMalloc((void **)&dm.d_img, m->img.size() * 4 + 4));
+    HIPCK(hipMemcpy(dm.d_model, &m->d, sizeof(DModel), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(dm.d_img, m->img.data(), m->img.size() * 4, hipMemcpyHostToDevice));
+    c->models[m->id] = dm;
+    *out = dm;
+    return ZPQ_OK;
+}
+
+// ------------------------------------------------------------------ batch core (device pointers)
+struct BatchArgs {
+    int nblocks;
+    const uint8_t *in; const uint64_t *in_off;
+    uint32_t flags;
+    uint8_t *out; const uint64_t *out_off;
+    uint32_t *out_len, *consumed, *final_code, *first_byte;
+    int32_t *status;
+    int32_t *trace; uint32_t ntrace;
+    uint32_t *ctx_out;
+    uint8_t *own_slot;   // zpq_block: use this slot instead of the pool
+};
+
+static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs &a)
+{
+    if (!c || !m) return ZPQ_E_ARG;
+    if (a.nblocks < 0) return ZPQ_E_ARG;
+    if (a.nblocks == 0) return ZPQ_OK;
+    if (!a.in_off || !a.out_off || !a.out_len || !a.status) return ZPQ_E_ARG;
+    HIPCK(hipSetDevice(c->device));
+    DevModel dm;
+    int rc = get_dev_model(c, m, &dm);
+    if (rc != ZPQ_OK) return rc;
+
+    const DModel &M = m->d;
+    const bool want_chain = M.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZB_CTX_ONLY)) && !a.trace &&
+                            zpq_chain_blocks_per_wg(&M) > 0;
+    DBatch B;
+    memset(&B, 0, sizeof B);
+    B.model = dm.d_model; B.img = dm.d_img;
+    B.nblocks = a.nblocks; B.flags = a.flags; B.ntrace = a.ntrace;
+    B.in = a.in; B.in_off = a.in_off; B.out = a.out; B.out_off = a.out_off;
+    B.out_len = a.out_len; B.consumed = a.consumed; B.final_code = a.final_code;
+    B.first_byte = a.first_byte; B.status = a.status; B.trace = a.trace; B.ctx_out = a.ctx_out;
+    B.squash = c->d_squash; B.stretch = c->d_stretch; B.dt = c->d_dt; B.dt2k = c->d_dt2k;
+    B.ns = c->d_ns; B.stretch_c = c->d_stretch_c;
+
+    const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)a.nblocks;
+    if (max_by_mem == 0 && !a.own_slot) return ZPQ_E_NOMEM;
+    int nslots, grid;
+    if (want_chain) {
+        const int bpw = zpq_chain_blocks_per_wg(&M);
+        int nwg = (a.nblocks + bpw - 1) / bpw;
+        const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
+        if (nwg > cap_wg) nwg = cap_wg;
+        if ((uint64_t)nwg * bpw > max_by_mem) nwg = (int)(max_by_mem / bpw);
+        if (nwg < 1) return ZPQ_E_NOMEM;
+        nslots = nwg * bpw;
+        grid = nwg;
+    } else {
+        nslots = a.nblocks;
+        const int cap_res = c->cus * 8;
+        if (nslots > cap_res) nslots = cap_res;
+        if (!a.own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
+        grid = nslots;
+    }
+    if (a.own_slot) {
+        if (a.nblocks != 1) return ZPQ_E_ARG;
+        B.slots = a.own_slot; nslots = 1; grid = 1;
+    } else {
+        rc = c->slots.ensure((size_t)nslots * M.slot_bytes);
+        if (rc != ZPQ_OK) return rc;
+        B.slots = (uint8_t *)c->slots.p;
+    }
+    B.nslots = nslots;
+    c->last_slots = nslots;
+
+    HIPCK(hipEventRecord(c->ev0, c->stream));
+    if (want_chain && !a.own_slot) {
+        rc = zpq_launch_chain(&B, &M, decode, grid, c->stream);
+        if (rc != ZPQ_OK) return rc;
+        c->last_name = zpq_chain_kernel_name(&M, decode);
+    } else {
+        zpq_launch_generic(&B, decode, grid, c->stream);
+        c->last_name = decode ? "k_generic<decode>" : "k_generic<encode>";
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+    return ZPQ_OK;
+}
+
+extern "C" int zpq_encode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
+                                     const uint64_t *in_off, uint32_t flags, uint8_t *out,
+                                     const uint64_t *out_off, uint32_t *out_len, int32_t *status)
+{
+    BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr, nullptr,
+                   status, nullptr, 0, nullptr, nullptr};
+    return run_batch(c, m, 0, a);
+}
+
+extern "C" int zpq_decode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
+                                     const uint64_t *in_off, uint32_t flags, uint8_t *out,
+                                     const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
+                                     uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+{
+    BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed, final_code,
+                   first_byte, status, nullptr, 0, nullptr, nullptr};
+    return run_batch(c, m, 1, a);
+}
+
+// ------------------------------------------------------------------ host-pointer forms
+static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, const uint8_t *in,
+                      const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
+                      uint32_t *out_len, uint32_t *consumed, uint32_t *final_code,
+                      uint32_t *first_byte, int32_t *status, uint8_t *own_slot, int32_t *trace,
+                      uint32_t ntrace, uint32_t *ctx_out, size_t ctx_words)
+{
+    if (!c || !m || nblocks < 0) return ZPQ_E_ARG;
+    if (nblocks == 0) return ZPQ_OK;
+    if (!in_off || !out_off || !out_len || !status) return ZPQ_E_ARG;
+    for (int b = 0; b < nblocks; b++)
+        if (in_off[b + 1] < in_off[b] || out_off[b + 1] < out_off[b] ||
+            in_off[b + 1] - in_off[b] > 0xFFFFFFF0ull || out_off[b + 1] - out_off[b] > 0xFFFFFFF0ull)
+            return ZPQ_E_ARG;
+    const size_t in_bytes = (size_t)in_off[nblocks], out_bytes = (size_t)out_off[nblocks];
+    if ((in_bytes && !in) || (out_bytes && !out)) return ZPQ_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCK(hipSetDevice(c->device));
+    int rc;
+    const size_t offb = (size_t)(nblocks + 1) * 8, u32b = (size_t)nblocks * 4;
+    if ((rc = c->s_in.ensure(in_bytes + 16)) || (rc = c->s_out.ensure(out_bytes + 16)) ||
+        (rc = c->s_inoff.ensure(offb)) || (rc = c->s_outoff.ensure(offb)) ||
+        (rc = c->s_status.ensure(u32b)))
+        return rc;
+    for (auto &b : c->s_u32) if ((rc = b.ensure(u32b))) return rc;
+    const size_t misc_bytes = (trace ? (size_t)ntrace * 4 : 0) + ctx_words * 4 + 16;
+    if ((rc = c->s_misc.ensure(misc_bytes))) return rc;
+    hipStream_t s = c->stream;
+    if (in_bytes) HIPCK(hipMemcpyAsync(c->s_in.p, in, in_bytes, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(c->s_inoff.p, in_off, offb, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(c->s_outoff.p, out_off, offb, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemsetAsync(c->s_status.p, 0xff, u32b, s));   // -1: "kernel never reported"
+    HIPCK(hipMemsetAsync(c->s_u32[0].p, 0, u32b, s));
+    if (misc_bytes > 16) HIPCK(hipMemsetAsync(c->s_misc.p, 0, misc_bytes, s));
+    BatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.nblocks = nblocks; a.in = (const uint8_t *)c->s_in.p; a.in_off = (const uint64_t *)c->s_inoff.p;
+    a.flags = flags; a.out = (uint8_t *)c->s_out.p; a.out_off = (const uint64_t *)c->s_outoff.p;
+    a.out_len = (uint32_t *)c->s_u32[0].p;
+    a.consumed = decode ? (uint32_t *)c->s_u32[1].p : nullptr;
+    a.final_code = decode ? (uint32_t *)c->s_u32[2].p : nullptr;
+    a.first_byte = decode ? (uint32_t *)c->s_u32[3].p : nullptr;
+    a.status = (int32_t *)c->s_status.p;
+    a.own_slot = own_slot;
+    if (trace) { a.trace = (int32_t *)c->s_misc.p; a.ntrace = ntrace; }
+    if (ctx_out) a.ctx_out = (uint32_t *)c->s_misc.p;
+    rc = run_batch(c, m, decode, a);
+    if (rc != ZPQ_OK) return rc;
+    HIPCK(hipMemcpyAsync(out_len, a.out_len, u32b, hipMemcpyDeviceToHost, s));
+    HIPCK(hipMemcpyAsync(status, a.status, u32b, hipMemcpyDeviceToHost, s));
+    if (decode && consumed) HIPCK(hipMemcpyAsync(consumed, a.consumed, u32b, hipMemcpyDeviceToHost, s));
+    if (decode && final_code) HIPCK(hipMemcpyAsync(final_code, a.final_code, u32b, hipMemcpyDeviceToHost, s));
+    if (decode && first_byte) HIPCK(hipMemcpyAsync(first_byte, a.first_byte, u32b, hipMemcpyDeviceToHost, s));
+    if (out_bytes) HIPCK(hipMemcpyAsync(out, c->s_out.p, out_bytes, hipMemcpyDeviceToHost, s));
+    if (trace) HIPCK(hipMemcpyAsync(trace, c->s_misc.p, (size_t)ntrace * 4, hipMemcpyDeviceToHost, s));
+    if (ctx_out) HIPCK(hipMemcpyAsync(ctx_out, c->s_misc.p, ctx_words * 4, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    return ZPQ_OK;
+}
+
+extern "C" int zpq_encode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
+                                 const uint64_t *in_off, uint32_t flags, uint8_t *out,
+                                 const uint64_t *out_off, uint32_t *out_len, int32_t *status)
+{
+    return host_batch(c, m, 0, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr,
+                      nullptr, status, nullptr, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
+                                 const uint64_t *in_off, uint32_t flags, uint8_t *out,
+                                 const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
+                                 uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+{
+    return host_batch(c, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed,
+                      final_code, first_byte, status, nullptr, nullptr, 0, nullptr, 0);
+}
+
+// ------------------------------------------------------------------ one block, many segments
+extern "C" int zpq_block_create(zpq_ctx *c, const zpq_model *m, zpq_block **out)
+{
+    if (!c || !m || !out) return ZPQ_E_ARG;
+    *out = nullptr;
+    HIPCK(hipSetDevice(c->device));
+    zpq_block *b = new (std::nothrow) zpq_block();
+    if (!b) return ZPQ_E_NOMEM;
+    b->ctx = c; b->model = m; b->fresh = true; b->slot = nullptr;
+    if (hipMalloc((void **)&b->slot, m->d.slot_bytes) != hipSuccess) { delete b; return ZPQ_E_NOMEM; }
+    *out = b;
+    return ZPQ_OK;
+}
+
+extern "C" void zpq_block_destroy(zpq_block *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->slot);
+    delete b;
+}
+
+extern "C" int zpq_block_encode_segment(zpq_block *b, const uint8_t *in, size_t n, uint32_t flags,
+                                        uint8_t *out, size_t cap, size_t *out_len)
+{
+    if (!b || !out_len || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
+    uint32_t olen = 0;
+    int32_t st = 0;
+    const uint32_t f = (flags & 0xffu) | ZPQ_FLAG_GENERIC | (b->fresh ? 0u : ZB_KEEP_STATE);
+    int rc = host_batch(b->ctx, b->model, 0, 1, in, in_off, f, out, out_off, &olen, nullptr, nullptr,
+                        nullptr, &st, b->slot, nullptr, 0, nullptr, 0);
+    if (rc != ZPQ_OK) return rc;
+    b->fresh = false;
+    *out_len = olen;
+    return st;
+}
+
+extern "C" int zpq_block_decode_segment(zpq_block *b, const uint8_t *in, size_t n, uint32_t flags,
+                                        uint8_t *out, size_t cap, size_t *out_len, size_t *consumed,
+                                        uint32_t *final_code, uint32_t *first_byte)
+{
+    if (!b || !out_len || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
+    uint32_t olen = 0, cons = 0, code = 0, first = 0xFFFFFFFFu;
+    int32_t st = 0;
+    const uint32_t f = (flags & 0xffu) | ZPQ_FLAG_GENERIC | (b->fresh ? 0u : ZB_KEEP_STATE);
+    int rc = host_batch(b->ctx, b->model, 1, 1, in, in_off, f, out, out_off, &olen, &cons, &code, &first,
+                        &st, b->slot, nullptr, 0, nullptr, 0);
+    if (rc != ZPQ_OK) return rc;
+    b->fresh = false;
+    *out_len = olen;
+    if (consumed) *consumed = cons;
+    if (final_code) *final_code = code;
+    if (first_byte) *first_byte = first;
+    return st;
+}
+
+// ------------------------------------------------------------------ test hooks
+extern "C" int zpq_debug_contexts(zpq_ctx *c, const zpq_model *m, const uint8_t *in, size_t n, uint32_t *h_out)
+{
+    if (!c || !m || !h_out || (n && !in)) return ZPQ_E_ARG;
+    if (m->d.n == 0 || n == 0) return ZPQ_OK;
+    const uint64_t in_off[2] = {0, n}, out_off[2] = {0, 0};
+    uint32_t olen = 0;
+    int32_t st = 0;
+    uint8_t dummy = 0;
+    int rc = host_batch(c, m, 0, 1, in, in_off, ZPQ_FLAG_GENERIC | ZB_CTX_ONLY, &dummy, out_off, &olen,
+                        nullptr, nullptr, nullptr, &st, nullptr, nullptr, 0, h_out, n * (size_t)m->d.n);
+    return rc != ZPQ_OK ? rc : st;
+}
+
+extern "C" int zpq_debug_encode_trace(zpq_ctx *c, const zpq_model *m, const uint8_t *in, size_t n,
+                                      uint32_t flags, uint8_t *out, size_t cap, size_t *out_len,
+                                      int32_t *p_trace, size_t ntrace)
+{
+    if (!c || !m || !out_len || !p_trace || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
+    uint32_t olen = 0;
+    int32_t st = 0;
+    int rc = host_batch(c, m, 0, 1, in, in_off, (flags & 0xffu) | ZPQ_FLAG_GENERIC, out, out_off, &olen,
+                        nullptr, nullptr, nullptr, &st, nullptr, p_trace, (uint32_t)ntrace, nullptr, 0);
+    if (rc != ZPQ_OK) return rc;
+    *out_len = olen;
+    return st;
+}

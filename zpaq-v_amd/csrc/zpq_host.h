@@ -1,0 +1,29 @@
+// zpq_host.h -- host-only internals of libzpaq_hip.so.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "zpq_common.h"
+
+namespace zpq {
+
+// Start-up tables exactly as the reference builds them (predictor.v:7-18).
+struct Tables {
+    int32_t squash[4096];
+    int32_t stretch[32768];
+    int32_t dt[1024];
+    int32_t dt2k[256];
+    uint8_t ns[1024];
+    uint32_t stretch_c[2048 + 128];  // LDS-sized packing of stretch (see zpq_model.cpp)
+};
+const Tables &tables(int *status);
+uint64_t tables_fnv(int which);
+
+}  // namespace zpq
+
+struct zpq_model {
+    DModel d;
+    std::vector<uint32_t> img;  // initial table contents (ICM/ISSE/SSE), uploaded per ctx
+    uint64_t id;                // unique, for the per-ctx device cache
+};
