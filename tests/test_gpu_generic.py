@@ -152,7 +152,8 @@ def test_generic_random_blocks_all_levels(zpq, gpu_ctx):
 
 def test_generic_overflow_and_status(zpq, gpu_ctx):
     model = zpq.Model(level=2)
-    data = bytes(random.Random(5).getrandbits(8) for _ in range(2000))
+    rnd = random.Random(5)
+    data = bytes(rnd.getrandbits(8) for _ in range(2000))
     coded, status, out_len = gpu_ctx.encode_blocks(model, [data], flags=zpq.FLAG_PP | zpq.FLAG_GENERIC, cap=100)
     assert status[0] == -7 and int(out_len[0]) == len(O.Codec(model.header).encode(data))
     good, status, _ = gpu_ctx.encode_blocks(model, [data], flags=zpq.FLAG_PP | zpq.FLAG_GENERIC)

@@ -534,6 +534,13 @@ __device__ void init_slot(const DBatch &B, u8 *slot, const int lane)
             u16 *a16 = reinterpret_cast<u16 *>(slot + c.a16_off);
             for (u32 i = lane; i < c.a16_len; i += 64) a16[i] = (u16)c.a16_fill;
         }
+        if (c.type == ZT_MATCH && lane == 0) {
+            // Quirk: Predictor.init leaves sizebits/bufbits in cr.a/cr.b (predictor.v:372-373),
+            // which predict/update then read as the initial match length and offset (:566-572).
+            DCompScal *gs = reinterpret_cast<DCompScal *>(slot + M.scal_off);
+            gs[ci].a = c.a;
+            gs[ci].b = c.b;
+        }
     }
     __syncthreads();
 }
