@@ -1,0 +1,136 @@
+"""GPU parity: the LDS-resident chain kernel (ICM + ISSE chain [+ MIX2], every
+shipped level) against the CPU oracle and the generic kernel, through the C ABI."""
+import hashlib
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import workload as W
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from inputs import INPUTS  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+
+
+def mixed_blocks(rnd, count, sizes):
+    blocks = []
+    for i in range(count):
+        n = rnd.choice(sizes)
+        kind = i % 4
+        if kind == 0:
+            b = bytes(n)
+        elif kind == 1:
+            b = bytes(rnd.getrandbits(8) for _ in range(n))
+        elif kind == 2:
+            b = bytes(rnd.choice(b"etaoin shrdlu\n") for _ in range(n))
+        else:
+            per = bytes(rnd.getrandbits(8) for _ in range(rnd.randint(1, 40)))
+            b = (per * (n // len(per) + 1))[:n]
+        blocks.append(b)
+    return blocks
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
+def test_chain_matches_golden_streams(zpq, gpu_ctx, level):
+    model = zpq.Model(level=level)
+    assert model.has_fast_path
+    for mode in ("pp", "raw"):
+        ks = [k for k in sorted(G["streams"]) if k.startswith("%d/" % level) and k.endswith(mode)]
+        blocks = [INPUTS[k.split("/")[1]] for k in ks]
+        flags = zpq.FLAG_PP if mode == "pp" else 0
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=flags)
+        assert gpu_ctx.last_kernel_name == "k_chain<encode>"
+        assert (status == 0).all()
+        for k, c in zip(ks, coded):
+            assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k
+        dec, status, consumed, code, first = gpu_ctx.decode_blocks(model, coded, cap=8192, flags=flags)
+        assert gpu_ctx.last_kernel_name == "k_chain<decode>"
+        assert (status == 0).all() and dec == blocks
+        assert [int(c) for c in consumed] == [G["streams"][k]["consumed"] for k in ks]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_chain_ragged_batch_vs_oracle(zpq, gpu_ctx, level):
+    """Ragged sizes (0, 1, odd, > one nibble row reuse), more blocks than one workgroup holds."""
+    rnd = random.Random(1000 + level)
+    hdr = O.level_header(level)
+    model = zpq.Model(level=level)
+    blocks = mixed_blocks(rnd, 70, [0, 1, 2, 3, 15, 16, 17, 255, 256, 257, 1000, 2500])
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert (status == 0).all()
+    want = O.encode_blocks(hdr, blocks, nthreads=4)
+    assert coded == want
+    dec, status, consumed, code, first = gpu_ctx.decode_blocks(model, coded, cap=4096)
+    assert (status == 0).all() and dec == blocks and (first == 0).all()
+    assert [int(c) for c in consumed] == [len(c) for c in coded]
+    # generic kernel agrees too (two independent device implementations)
+    coded_g, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=zpq.FLAG_PP | zpq.FLAG_GENERIC)
+    assert coded_g == coded
+
+
+def test_chain_level2_64k_blocks_all_classes(zpq, gpu_ctx):
+    """The bench workload's four block classes at full 64 KiB size, level 2."""
+    hdr = O.level_header(2)
+    model = zpq.Model(level=2)
+    arr = W.make_blocks(8, 65536)
+    blocks = [arr[i].tobytes() for i in range(8)]
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks, cap=80000)
+    assert (status == 0).all()
+    want = O.encode_blocks(hdr, blocks, nthreads=8, slack=80000)
+    assert coded == want
+    dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=65536)
+    assert (status == 0).all() and dec == blocks
+
+
+def test_chain_slot_reuse_more_blocks_than_slots(zpq, gpu_ctx):
+    """Persistent groups re-initialise their slot between blocks: restrict the
+    state budget so that 40 blocks share 16 slots."""
+    model = zpq.Model(level=2)
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 17 * model.state_bytes)
+    try:
+        rnd = random.Random(77)
+        blocks = mixed_blocks(rnd, 40, [300, 1200, 2048])
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_slots == 16
+        assert (status == 0).all()
+        assert coded == O.encode_blocks(O.level_header(2), blocks, nthreads=4)
+        dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=4096)
+        assert (status == 0).all() and dec == blocks
+    finally:
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+
+
+def test_chain_generic_vm_program(zpq, gpu_ctx):
+    """A chain model whose HCOMP is NOT one of the recognised shapes goes through
+    the in-kernel ZPAQL interpreter."""
+    hdr = bytes([3, 8, 0, 0, 2, 3, 16, 8, 16, 0, 0,
+                 104, 17, 95, 0, 59, 135, 7, 112, 25, 60, 59, 112, 56, 0])
+    offs = O.scan_header(hdr)
+    model = zpq.Model(header=hdr)
+    assert model.has_fast_path
+    rnd = random.Random(5)
+    blocks = mixed_blocks(rnd, 12, [100, 700, 1500])
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert gpu_ctx.last_kernel_name == "k_chain<encode>"
+    assert (status == 0).all()
+    assert coded == O.encode_blocks(hdr, blocks, nthreads=4)
+    dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=2048)
+    assert (status == 0).all() and dec == blocks
+
+
+def test_chain_overflow_status(zpq, gpu_ctx):
+    model = zpq.Model(level=2)
+    rnd = random.Random(5)
+    data = bytes(rnd.getrandbits(8) for _ in range(2000))
+    coded, status, out_len = gpu_ctx.encode_blocks(model, [data], cap=100)
+    assert status[0] == -7 and int(out_len[0]) == len(O.Codec(model.header).encode(data))
+    good, status, _ = gpu_ctx.encode_blocks(model, [data])
+    dec, status, *_ = gpu_ctx.decode_blocks(model, good, cap=100)
+    assert status[0] == -7

@@ -1,8 +1,567 @@
-// placeholder until the LDS-resident chain kernel lands (next commit)
+// zpq_chain.hip -- the LDS-resident kernel for "chain" models: component 0 is an
+// ICM, every further component is an ISSE fed by its predecessor (j = i-1) and
+// the last may be a MIX2.  That is every level the reference ships
+// (levels.v:53-375: level 1 = ICM+ISSE ... level 5 = ICM+7xISSE+MIX2).
+//
+// Mapping (gfx950, wave64):
+//   * one ZPAQ block = one GROUP of G=16 lanes (one DPP row); a wave carries 4
+//     blocks, a workgroup W waves.  Lane c of a group owns component c.
+//   * per block in LDS: ICM cm[256] (1 KiB) and each ISSE's weight pairs
+//     cm[512] (2 KiB).  Shared per workgroup in LDS: squash (i16[4096]), the
+//     state table ns[1024] and a 8.5 KiB packing of the 64 KiB stretch table.
+//   * per block in HBM (its state slot): the hash tables (64*2^sizebits bytes per
+//     component), M/H for the ZPAQL VM, MIX2 weights.  A nibble's bit-history
+//     row (16 B: check byte + 15 states) is fetched as h0 / h0^16 / h0^32 from
+//     ONE 64-byte line, kept in 4 VGPRs for the nibble's four bits, and written
+//     back once (predictor.v:495-532,558-563,619-622,704,790).
+//   * the prediction chain p0 -> p1 -> ... is handed lane-to-lane with DPP
+//     row_shr:1; the final probability and (when decoding) the decoded bit are
+//     broadcast inside the row with ds_bpermute.
+//   * the arithmetic coder (encoder.v:48-89 / decoder.v:73-118) runs on the lane
+//     that owns the last component.
+// All arithmetic is integer and reproduces V's 32-bit wrap/arithmetic-shift
+// semantics; results are bit-identical to zpq_generic.hip and the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <vector>
+
 #include "../../include/zpaq_hip.h"
 #include "zpq_common.h"
-extern "C" int zpq_chain_blocks_per_wg(const DModel *) { return 0; }
-extern "C" int zpq_chain_max_wgs(const DModel *, int) { return 0; }
-extern "C" int zpq_launch_chain(const DBatch *, const DModel *, int, int, hipStream_t) { return ZPQ_E_INTERNAL; }
-extern "C" const char *zpq_chain_kernel_name(const DModel *, int) { return ""; }
+
+namespace zpqc {
+
+typedef int32_t i32;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint8_t u8;
+typedef uint16_t u16;
+
+constexpr int G = 16;          // lanes per ZPAQ block (= one DPP row)
+constexpr int BPW = 64 / G;    // blocks per wave
+constexpr int MAXW = 8;        // waves per workgroup upper bound
+
+// LDS layout of the shared read-only tables
+constexpr int LDS_STRETCH = 0;                   // u32[2048+128]
+constexpr int LDS_SQUASH = (2048 + 128) * 4;     // u16[4096]
+constexpr int LDS_NS = LDS_SQUASH + 4096 * 2;    // u8[1024]
+constexpr int LDS_STATE = LDS_NS + 1024;         // per-block state follows (16-B aligned)
+
+// HCOMP program shapes the kernel evaluates in registers instead of interpreting
+enum { VM_GENERIC = 0, VM_HASHCHAIN = 1, VM_LEVEL1 = 2 };
+
+struct Cfg {
+    int32_t n;                 // components
+    int32_t nisse_end;         // components 1..nisse_end-1 are ISSE (chain length incl. ICM)
+    int32_t has_mix2;          // last component is MIX2
+    int32_t blocks_per_wg;
+    int32_t lds_per_block;     // bytes
+    int32_t vm_kind;
+    uint16_t lds_off[G];       // byte offset of component c's table inside the block's LDS state
+};
+
+__device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+__device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
+__device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
+__device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
+
+// value of lane (li-1) of the same 16-lane row; lane 0 of a row gets `self`
+__device__ __forceinline__ i32 row_shr1(i32 self)
+{
+    return __builtin_amdgcn_update_dpp(self, self, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+}
+// broadcast from lane `src` (0..15) of the own row
+__device__ __forceinline__ i32 row_bcast(i32 v, int src_lane_abs)
+{
+    return __builtin_amdgcn_ds_bpermute(src_lane_abs << 2, v);
+}
+
+__device__ __forceinline__ u32 row_byte(const uint4 &r, u32 slot)
+{
+    const u32 d = (slot & 8) ? ((slot & 4) ? r.w : r.z) : ((slot & 4) ? r.y : r.x);
+    return (d >> ((slot & 3) * 8)) & 255u;
+}
+__device__ __forceinline__ void row_set(uint4 &r, u32 slot, u32 v)
+{
+    const u32 sh = (slot & 3) * 8;
+    const u32 m = ~(255u << sh), b = v << sh;
+    const u32 q = slot >> 2;
+    r.x = (q == 0) ? ((r.x & m) | b) : r.x;
+    r.y = (q == 1) ? ((r.y & m) | b) : r.y;
+    r.z = (q == 2) ? ((r.z & m) | b) : r.z;
+    r.w = (q == 3) ? ((r.w & m) | b) : r.w;
+}
+
+// ---- generic ZPAQL interpreter (zpaql.v:167-954) for programs that are not one
+//      of the recognised shapes; runs on lane 0 of the group, M/H/R in the slot.
+struct Vm {
+    u32 a, b, c, d;
+    i32 f, pc;
+    u8 *m; u32 mlen;
+    u32 *h; u32 hlen;
+    u32 *r;
+    const u8 *hdr;
+    i32 hdr_len, hbegin, hend;
+};
+__device__ __forceinline__ u32 m_get(const Vm &z, u32 i) { return z.mlen ? z.m[i & (z.mlen - 1)] : 0u; }
+__device__ __forceinline__ void m_set(Vm &z, u32 i, u32 v) { if (z.mlen) z.m[i & (z.mlen - 1)] = (u8)v; }
+__device__ __forceinline__ u32 h_get(const Vm &z, u32 i) { return z.hlen ? z.h[i & (z.hlen - 1)] : 0u; }
+__device__ __forceinline__ void h_set(Vm &z, u32 i, u32 v) { if (z.hlen) z.h[i & (z.hlen - 1)] = v; }
+__device__ u32 vm_src(const Vm &z, int s, u32 operand)
+{
+    switch (s) {
+    case 0: return z.a;
+    case 1: return z.b;
+    case 2: return z.c;
+    case 3: return z.d;
+    case 4: return m_get(z, z.b);
+    case 5: return m_get(z, z.c);
+    case 6: return h_get(z, z.d);
+    default: return operand;
+    }
+}
+__device__ void vm_dst(Vm &z, int t, u32 v)
+{
+    switch (t) {
+    case 0: z.a = v; break;
+    case 1: z.b = v; break;
+    case 2: z.c = v; break;
+    case 3: z.d = v; break;
+    case 4: m_set(z, z.b, v); break;
+    case 5: m_set(z, z.c, v); break;
+    default: h_set(z, z.d, v); break;
+    }
+}
+__device__ bool vm_run(Vm &z, u32 input)
+{
+    z.a = input;
+    z.pc = z.hbegin;
+    u32 steps = 0;
+    while (z.pc < z.hend && z.pc >= z.hbegin) {
+        u32 op = z.hdr[z.pc++];
+        u32 operand = 0;
+        if ((op & 7) == 7 && op != 255 && z.pc < z.hdr_len) operand = z.hdr[z.pc++];
+        else if (op == 255 && z.pc + 1 < z.hdr_len) { operand = z.hdr[z.pc] + z.hdr[z.pc + 1] * 256u; z.pc += 2; }
+        const i32 rel = (i32)((operand + 128) & 255) - 127;
+        bool go = true;
+        if (op < 56) {
+            const int t = op >> 3, k = op & 7;
+            if (k == 0) { if (t) { u32 tmp = vm_src(z, t, 0); vm_dst(z, t, z.a); z.a = tmp; } }
+            else if (k == 1) vm_dst(z, t, vm_src(z, t, 0) + 1);
+            else if (k == 2) vm_dst(z, t, vm_src(z, t, 0) - 1);
+            else if (k == 3) vm_dst(z, t, ~vm_src(z, t, 0));
+            else if (k == 4) vm_dst(z, t, 0);
+            else if (k == 7) {
+                if (t <= 3) vm_dst(z, t, z.r[operand & 255]);
+                else if (t == 4) { if (z.f != 0) z.pc += rel; }
+                else if (t == 5) { if (z.f == 0) z.pc += rel; }
+                else z.r[operand & 255] = z.a;
+            } else go = false;
+        } else if (op < 64) {
+            if (op == 56) go = false;
+            else if (op == 57) {}
+            else if (op == 59) z.a = (z.a + m_get(z, z.b) + 512u) * 773u;
+            else if (op == 60) h_set(z, z.d, (h_get(z, z.d) + z.a + 512u) * 773u);
+            else if (op == 63) z.pc += rel;
+            else go = false;
+        } else if (op < 120) vm_dst(z, (int)(op - 64) >> 3, vm_src(z, op & 7, operand));
+        else if (op < 128) go = false;
+        else if (op < 216) {
+            const u32 v = vm_src(z, op & 7, operand);
+            switch ((op - 128) >> 3) {
+            case 0: z.a += v; break;
+            case 1: z.a -= v; break;
+            case 2: z.a *= v; break;
+            case 3: if (v) z.a /= v; break;
+            case 4: if (v) z.a %= v; break;
+            case 5: z.a &= v; break;
+            case 6: z.a &= ~v; break;
+            case 7: z.a |= v; break;
+            case 8: z.a ^= v; break;
+            case 9: z.a <<= (v & 31); break;
+            default: z.a >>= (v & 31); break;
+            }
+        } else if (op < 240) {
+            const u32 v = vm_src(z, op & 7, operand);
+            const int g = (op - 216) >> 3;
+            z.f = g == 0 ? (z.a == v) : (g == 1 ? (z.a < v) : (z.a > v));
+        } else if (op == 255) {
+            if (z.pc < 2) go = false;
+            else {
+                z.pc = z.hbegin + (i32)z.hdr[z.pc - 2] + (i32)z.hdr[z.pc - 1] * 256;
+                if (z.pc >= z.hend) go = false;
+            }
+        } else go = false;
+        if (!go) break;
+        if (++steps >= ZPQ_VM_STEP_CAP) return false;
+    }
+    return true;
+}
+
+template <bool DEC>
+__global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const DModel &M = *B.model;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    // ---- shared read-only tables -> LDS
+    {
+        u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
+        for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
+        u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        u8 *ns = lds + LDS_NS;
+        for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
+    }
+    __syncthreads();
+    const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
+    const u8 *s_ns = lds + LDS_NS;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / G, li = lane % G;
+    const int row_base = lane & ~(G - 1);              // absolute lane of the row's lane 0
+    const int bslot = wave * BPW + grp;                // block slot inside the workgroup
+    const int slot_id = blockIdx.x * cfg.blocks_per_wg + bslot;
+    const int nslots = gridDim.x * cfg.blocks_per_wg;
+    u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
+    u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
+
+    const int n = cfg.n;
+    const int last = n - 1;                            // lane that owns the final prediction + coder
+    const int ctype = (li < n) ? M.comp[li].type : 0;
+    const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
+    const DComp &C = M.comp[li < n ? li : 0];
+    u8 *ht = slot + C.ht_off;
+    const u32 ht_mask = C.ht_len - 16u;
+    const int sizebits = C.a + 2;
+    u32 *cm32 = reinterpret_cast<u32 *>(my + cfg.lds_off[li < n ? li : 0]);
+    u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
+    const int mix_j = M.comp[last].j, mix_k = M.comp[last].k, mix_rate = M.comp[last].rate;
+    const u32 mix_mask = (u32)M.comp[last].mask, mix_cmask = (u32)(M.comp[last].c - 1);
+
+    for (int blk = slot_id; blk < B.nblocks; blk += nslots) {
+        // ---- Predictor.init + ZPAQL.clear for this block (predictor.v:325-470, zpaql.v:54-95):
+        //      the 16 lanes of the group zero the whole slot with 16-B stores, then fill LDS.
+        {
+            uint4 *z4 = reinterpret_cast<uint4 *>(slot);
+            const u64 n16 = M.zero_bytes / 16;
+            const uint4 zero = make_uint4(0, 0, 0, 0);
+            for (u64 i = li; i < n16; i += G) z4[i] = zero;
+            for (int c = 0; c < n; c++) {
+                const DComp &cc = M.comp[c];
+                u32 *dst = reinterpret_cast<u32 *>(my + cfg.lds_off[c]);
+                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) dst[i] = B.img[i];
+                else if (cc.type == ZT_ISSE) for (int i = li; i < 512; i += G) dst[i] = B.img[256 + i];
+                else if (cc.type == ZT_MIX2) {
+                    u32 *w = reinterpret_cast<u32 *>(slot + cc.a16_off);
+                    const u32 words = (cc.a16_len + 1) / 2;
+                    for (u32 i = li; i < words; i += G) w[i] = 0x80008000u;   // a16[] = 32768 (predictor.v:396)
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        const u8 *src = B.in + B.in_off[blk];
+        const u32 nin = (u32)(B.in_off[blk + 1] - B.in_off[blk]);
+        u8 *dst = B.out + B.out_off[blk];
+        const u32 cap = (u32)(B.out_off[blk + 1] - B.out_off[blk]);
+        i32 status = ZPQ_OK;
+
+        // ZPAQL state
+        Vm z;
+        z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0;
+        z.m = slot + M.m_off; z.mlen = M.mlen;
+        z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
+        z.r = reinterpret_cast<u32 *>(slot + M.r_off);
+        z.hdr = M.header; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
+        u32 prev = 0;          // VM_HASHCHAIN: M[b] of the next run (the byte stored by the previous run)
+        u32 m4 = 0, b4 = 0;    // VM_LEVEL1: the 4-byte M and B
+        u32 hctx = 0;          // this lane's H[li] (Predictor.h[li])
+
+        // coder state (meaningful on lane `last`)
+        u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, ipos = 0;
+        u32 first = 0xFFFFFFFFu;
+        bool got_first = false;
+        if (DEC) {
+            for (int k = 0; k < 4; k++) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+        }
+        const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
+
+        for (u32 bi = 0; bi < total; bi++) {
+            u32 ch = 0;
+            if (!DEC) {
+                if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : src[bi - 1];
+                else ch = src[bi];
+            }
+            // ---- EOF flag: encode(0,0) / decode(0)  (encoder.v:108, decoder.v:128)
+            if (!DEC) {
+                if (li == last) {
+                    low += 1;                               // p=0, y=0: mid = low, low = mid+1
+                    while ((high ^ low) < 0x1000000u) {
+                        if (opos < cap) dst[opos] = (u8)(high >> 24);
+                        opos++;
+                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                    }
+                }
+            } else {
+                i32 eof = 0;
+                if (li == last) {
+                    if (code <= low) { eof = 1; high = low; } else { low = low + 1; }   // p=0: mid = low
+                    while ((high ^ low) < 0x1000000u) {
+                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                        u32 c = 0; if (ipos < nin) c = src[ipos++];
+                        code = (code << 8) | c;
+                    }
+                }
+                eof = row_bcast(eof, row_base + last);
+                if (eof) break;
+            }
+
+            u32 c8 = 1, slotn = 1;
+            uint4 R = make_uint4(0, 0, 0, 0);
+            u8 *raddr = ht;
+#pragma unroll 1
+            for (int bit = 7; bit >= 0; bit--) {
+                // ---- nibble start: find_ht (predictor.v:495-532) on every hashed lane
+                if ((bit & 3) == 3 && hashed) {
+                    const u32 cx = hctx + 16u * c8;
+                    const u32 chk = (cx >> sizebits) & 255u;
+                    const u32 h0 = (cx * 16u) & ht_mask;
+                    const uint4 A = *reinterpret_cast<const uint4 *>(ht + h0);
+                    const uint4 Bq = *reinterpret_cast<const uint4 *>(ht + (h0 ^ 16u));
+                    const uint4 Cq = *reinterpret_cast<const uint4 *>(ht + (h0 ^ 32u));
+                    if ((A.x & 255u) == chk) { R = A; raddr = ht + h0; }
+                    else if ((Bq.x & 255u) == chk) { R = Bq; raddr = ht + (h0 ^ 16u); }
+                    else if ((Cq.x & 255u) == chk) { R = Cq; raddr = ht + (h0 ^ 32u); }
+                    else {
+                        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+                        if (qa <= qb && qa <= qc) raddr = ht + h0;
+                        else if (qb < qc) raddr = ht + (h0 ^ 16u);
+                        else raddr = ht + (h0 ^ 32u);
+                        R = make_uint4(chk, 0, 0, 0);
+                    }
+                }
+                // ---- predict (predictor.v:555-563,586-599,615-631,667)
+                const u32 s = row_byte(R, slotn);
+                i32 p = 0, w0 = 0, w1 = 0, pin = 0;
+                u32 cmv = 0, mcx = 0;
+                if (ctype == ZT_ICM) {
+                    cmv = cm32[s];
+                    u32 q = cmv >> 8;
+                    q = q < 1u ? 1u : q;                         // stretch(): idx<1 -> 1
+                    const u32 wv = s_stretch[q >> 4];
+                    const u32 k = q & 15u;
+                    i32 mid = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << k) - 1u) & 0xFFFEu);
+                    const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+                    const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+                    p = (q < 64u || q >= 32704u) ? endv : mid;
+                } else if (ctype == ZT_ISSE) {
+                    const uint2 wv = *reinterpret_cast<const uint2 *>(cm32 + s * 2);
+                    w0 = (i32)wv.x; w1 = (i32)wv.y;
+                }
+                for (int i = 1; i < cfg.nisse_end; i++) {
+                    const i32 pv = row_shr1(p);
+                    if (li == i) { pin = pv; p = clamp2k(wadd(wmul(w0, pv), wmul(w1, 64)) >> 16); }
+                }
+                i32 pj = 0, pk = 0, wmix = 0;
+                if (cfg.has_mix2) {
+                    pj = row_bcast(p, row_base + mix_j);
+                    pk = row_bcast(p, row_base + mix_k);
+                    if (li == last) {
+                        mcx = (hctx + (c8 & mix_mask)) & mix_cmask;
+                        wmix = a16[mcx];
+                        p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                    }
+                }
+                i32 sqi = wadd(p, 2047);
+                sqi = min(max(sqi, 0), 4093);
+                const i32 sq = s_squash[sqi];                // squash(p[li]) (predictor.v:193-202)
+
+                // ---- code the bit on lane `last` (encoder.v:48-89 / decoder.v:73-118)
+                i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
+                if (li == last) {
+                    const u32 p16 = (u32)sq * 2u + 1u;
+                    const u32 mid = low + (u32)(((u64)(high - low) * p16) >> 16);
+                    if (DEC) y = code <= mid ? 1 : 0;
+                    if (y) high = mid; else low = mid + 1;
+                    while ((high ^ low) < 0x1000000u) {
+                        if (!DEC) { if (opos < cap) dst[opos] = (u8)(high >> 24); opos++; }
+                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                        if (DEC) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+                    }
+                }
+                if (DEC) y = row_bcast(y, row_base + last);
+
+                // ---- update (predictor.v:701-709,744-762,776-791)
+                if (ctype == ZT_ICM) {
+                    cm32[s] = (u32)wadd((i32)cmv, (y * 32767 - (i32)(cmv >> 8)) >> 2);
+                } else if (ctype == ZT_ISSE) {
+                    const i32 err = y * 32767 - sq;
+                    const i32 nw0 = clamp512k(wadd(w0, wadd(wmul(err, pin), 1 << 12) >> 13));
+                    const i32 nw1 = clamp512k(wadd(w1, (err + 16) >> 5));
+                    *reinterpret_cast<uint2 *>(cm32 + s * 2) = make_uint2((u32)nw0, (u32)nw1);
+                } else if (ctype == ZT_MIX2) {
+                    const i32 err = wmul(y * 32767 - sq, mix_rate) >> 5;
+                    i32 w = wadd(wmix, wadd(wmul(err, pj - pk), 1 << 12) >> 13);
+                    w = min(max(w, 0), 65535);
+                    a16[mcx] = (u16)w;
+                }
+                if (hashed) row_set(R, slotn, s_ns[s * 4 + y]);
+                // ---- bit context (predictor.v:807-823)
+                c8 = (c8 << 1) | (u32)y;
+                slotn = ((bit & 3) == 0) ? 1u : ((slotn * 2 + (u32)y) & 15u);
+                if ((bit & 3) == 0 && hashed) *reinterpret_cast<uint4 *>(raddr) = R;
+            }
+            const u32 byte = c8 - 256;
+
+            // ---- ZPAQL.run(byte) and h[] copy (predictor.v:809-816)
+            if (cfg.vm_kind == VM_HASHCHAIN) {
+                // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
+                u32 a = byte;
+                u32 hv = 0;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; if (k == li) hv = a; }
+                hctx = hv;
+                prev = byte;
+            } else if (cfg.vm_kind == VM_LEVEL1) {
+                // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
+                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                u32 a = 0;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                const u32 h0v = a; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                hctx = (li == 0) ? h0v : ((li == 1) ? a : 0u);
+            } else {
+                if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                hctx = (li < n && (u32)li < M.hlen) ? z.h[li] : 0u;
+            }
+
+            if (DEC) {
+                if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
+                else {
+                    if (li == last && opos < cap) dst[opos] = (u8)byte;
+                    opos++;                                   // uniform across the group when decoding
+                    if (opos > cap) break;
+                }
+            }
+        }
+
+        // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139) / EOF bookkeeping
+        if (!DEC && li == last) {
+            high = low;                                        // encode(1, 0): mid = low, high = mid
+            while ((high ^ low) < 0x1000000u) {
+                if (opos < cap) dst[opos] = (u8)(high >> 24);
+                opos++;
+                low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+            }
+            for (int sft = 24; sft >= 0; sft -= 8) {
+                if (opos < cap) dst[opos] = (u8)(high >> sft);
+                opos++;
+            }
+        }
+        const i32 st0 = row_bcast(status, row_base);           // VM status lives on lane 0
+        if (li == last) {
+            i32 st = st0;
+            if (opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
+            B.out_len[blk] = opos;
+            B.status[blk] = st;
+            if (DEC) {
+                if (B.consumed) B.consumed[blk] = ipos;
+                if (B.final_code) B.final_code[blk] = code;
+                if (B.first_byte) B.first_byte[blk] = first;
+            }
+        }
+    }
+}
+
+}  // namespace zpqc
+
+// ------------------------------------------------------------------ host side
+using zpqc::Cfg;
+
+static bool build_cfg(const DModel *M, Cfg *cfg)
+{
+    if (!M->fast_kind || M->n < 1 || M->n > zpqc::G) return false;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->n = M->n;
+    int off = 0, i = 0;
+    if (M->comp[0].type != ZT_ICM) return false;
+    cfg->lds_off[0] = (uint16_t)off; off += 1024;
+    for (i = 1; i < M->n && M->comp[i].type == ZT_ISSE; i++) {
+        if (M->comp[i].b != i - 1) return false;               // chain: ISSE i is fed by component i-1
+        cfg->lds_off[i] = (uint16_t)off; off += 2048;
+    }
+    cfg->nisse_end = i;
+    if (i < M->n) {
+        if (i != M->n - 1 || M->comp[i].type != ZT_MIX2) return false;
+        if (M->comp[i].j >= i || M->comp[i].k >= i) return false;
+        cfg->has_mix2 = 1;
+        cfg->lds_off[i] = 0;
+    }
+    cfg->lds_per_block = off;
+    // recognise the shipped HCOMP programs (levels.v:73-87,126-141,...)
+    cfg->vm_kind = zpqc::VM_GENERIC;
+    const uint8_t *p = M->header + M->hbegin;
+    const int plen = M->hend - M->hbegin;
+    {
+        std::vector<uint8_t> want = {74, 18, 104, 95, 0};
+        for (int k = 0; k < M->n - 1; k++) { want.push_back(59); want.push_back(112); want.push_back(25); }
+        want.push_back(59); want.push_back(112); want.push_back(56);
+        if (plen == (int)want.size() && memcmp(p, want.data(), want.size()) == 0 && M->mlen >= 2 &&
+            M->hlen >= (uint32_t)M->n)
+            cfg->vm_kind = zpqc::VM_HASHCHAIN;
+        static const uint8_t l1[] = {96, 4, 28, 59, 10, 59, 112, 25, 10, 59, 10, 59, 112, 56};
+        if (plen == (int)sizeof l1 && memcmp(p, l1, sizeof l1) == 0 && M->mlen == 4 && M->hlen == 2 && M->n == 2)
+            cfg->vm_kind = zpqc::VM_LEVEL1;
+    }
+    const int avail = 160 * 1024 - zpqc::LDS_STATE - 256;
+    int bpw = avail / cfg->lds_per_block;
+    if (bpw > zpqc::MAXW * zpqc::BPW) bpw = zpqc::MAXW * zpqc::BPW;
+    bpw = bpw / zpqc::BPW * zpqc::BPW;
+    // 16 blocks per workgroup (4 waves, one per SIMD) unless the model's LDS state is bigger
+    if (bpw > 16) bpw = 16;
+    if (bpw < zpqc::BPW) return false;
+    cfg->blocks_per_wg = bpw;
+    return true;
+}
+
+extern "C" int zpq_chain_blocks_per_wg(const DModel *M)
+{
+    Cfg cfg;
+    return build_cfg(M, &cfg) ? cfg.blocks_per_wg : 0;
+}
+
+extern "C" int zpq_chain_max_wgs(const DModel *M, int cus)
+{
+    (void)M;
+    return cus;   // one workgroup per CU (LDS-bound)
+}
+
+extern "C" const char *zpq_chain_kernel_name(const DModel *, int decode)
+{
+    return decode ? "k_chain<decode>" : "k_chain<encode>";
+}
+
+extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, hipStream_t stream)
+{
+    Cfg cfg;
+    if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
+    const int threads = cfg.blocks_per_wg / zpqc::BPW * 64;
+    const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (decode) hipLaunchKernelGGL(zpqc::k_chain<true>, dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+    else hipLaunchKernelGGL(zpqc::k_chain<false>, dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+    return ZPQ_OK;
+}
