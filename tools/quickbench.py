@@ -6,11 +6,13 @@ import __graft_entry__ as ge
 import workload as W
 ap=argparse.ArgumentParser(); ap.add_argument('--blocks',type=int,default=256); ap.add_argument('--level',type=int,default=2)
 ap.add_argument('--size',type=int,default=65536); ap.add_argument('--reps',type=int,default=2); ap.add_argument('--generic',action='store_true')
-ap.add_argument('--check',type=int,default=4)
+ap.add_argument('--check',type=int,default=4); ap.add_argument('--cls',type=int,default=-1)
 a=ap.parse_args()
 z=ge.load(); ctx=z.Context(0); model=z.Model(level=a.level)
 nb=a.blocks; size=a.size
 arr=W.make_blocks_fast(nb,size)
+if a.cls>=0:
+    arr=np.stack([W.make_block(4*i+a.cls if a.cls!=2 else 2,size) for i in range(nb)])
 dev=torch.device('cuda:0')
 d_in=torch.from_numpy(arr.reshape(-1)).to(dev)
 cap=size+size//8+1024

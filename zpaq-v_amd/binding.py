@@ -112,8 +112,8 @@ class Model:
             "zpq_model_create")
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().zpq_model_destroy(self.h)
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.zpq_model_destroy(self.h)
             self.h = None
 
     @property
@@ -145,8 +145,8 @@ class Context:
         _ck(lib().zpq_ctx_create(device, C.byref(self.h)), "zpq_ctx_create")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().zpq_ctx_destroy(self.h)
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.zpq_ctx_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -244,8 +244,8 @@ class Block:
         _ck(lib().zpq_block_create(ctx.h, model.h, C.byref(self.h)), "zpq_block_create")
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().zpq_block_destroy(self.h)
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.zpq_block_destroy(self.h)
             self.h = None
 
     __del__ = close

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/zpaq_hip.h"
@@ -36,6 +37,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef uint8_t u8;
 typedef uint16_t u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G = 16;          // lanes per ZPAQ block (= one DPP row)
 constexpr int BPW = 64 / G;    // blocks per wave
@@ -57,6 +59,7 @@ struct Cfg {
     int32_t blocks_per_wg;
     int32_t lds_per_block;     // bytes
     int32_t vm_kind;
+    int32_t lds_trash;         // byte offset of the scratch table idle / MIX2 lanes read and write
     uint16_t lds_off[G];       // byte offset of component c's table inside the block's LDS state
 };
 
@@ -198,6 +201,16 @@ __device__ bool vm_run(Vm &z, u32 input)
     return true;
 }
 
+// One coded bit for every lane of the group.  K = bit index inside the nibble
+// (0..3) selects at compile time which dword(s) of the 16-byte row can hold the
+// bit-history slot: slot 1 | 2..3 | 4..7 | 8..15 (predictor.v:817-823).
+struct BitCtx {
+    u32 r0, r1, r2, r3;      // the nibble's bit-history row (byte 0 = check)
+    u32 slot;                // hmap4 & 15
+    u32 c8;
+    u32 low, high, code, opos, ipos;
+};
+
 template <bool DEC>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
@@ -221,29 +234,31 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / G, li = lane % G;
-    const int row_base = lane & ~(G - 1);              // absolute lane of the row's lane 0
-    const int bslot = wave * BPW + grp;                // block slot inside the workgroup
+    const int row_base = lane & ~(G - 1);
+    const int bslot = wave * BPW + grp;
     const int slot_id = blockIdx.x * cfg.blocks_per_wg + bslot;
     const int nslots = gridDim.x * cfg.blocks_per_wg;
     u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
     u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
 
     const int n = cfg.n;
-    const int last = n - 1;                            // lane that owns the final prediction + coder
+    const int last = n - 1;
     const int ctype = (li < n) ? M.comp[li].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
+    const bool is_icm = ctype == ZT_ICM, is_isse = ctype == ZT_ISSE, is_last = li == last;
     const DComp &C = M.comp[li < n ? li : 0];
     u8 *ht = slot + C.ht_off;
     const u32 ht_mask = C.ht_len - 16u;
     const int sizebits = C.a + 2;
-    u32 *cm32 = reinterpret_cast<u32 *>(my + cfg.lds_off[li < n ? li : 0]);
+    // every lane owns a table of 8-byte entries: ICM {cm, 0}, ISSE {w0, w1}; idle and MIX2
+    // lanes point at a per-block scratch table so that no role branch is needed per bit
+    uint2 *tab = reinterpret_cast<uint2 *>(my + (hashed ? cfg.lds_off[li] : cfg.lds_trash));
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const int mix_j = M.comp[last].j, mix_k = M.comp[last].k, mix_rate = M.comp[last].rate;
     const u32 mix_mask = (u32)M.comp[last].mask, mix_cmask = (u32)(M.comp[last].c - 1);
 
     for (int blk = slot_id; blk < B.nblocks; blk += nslots) {
-        // ---- Predictor.init + ZPAQL.clear for this block (predictor.v:325-470, zpaql.v:54-95):
-        //      the 16 lanes of the group zero the whole slot with 16-B stores, then fill LDS.
+        // ---- Predictor.init + ZPAQL.clear for this block (predictor.v:325-470, zpaql.v:54-95)
         {
             uint4 *z4 = reinterpret_cast<uint4 *>(slot);
             const u64 n16 = M.zero_bytes / 16;
@@ -251,9 +266,10 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             for (u64 i = li; i < n16; i += G) z4[i] = zero;
             for (int c = 0; c < n; c++) {
                 const DComp &cc = M.comp[c];
-                u32 *dst = reinterpret_cast<u32 *>(my + cfg.lds_off[c]);
-                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) dst[i] = B.img[i];
-                else if (cc.type == ZT_ISSE) for (int i = li; i < 512; i += G) dst[i] = B.img[256 + i];
+                uint2 *dst = reinterpret_cast<uint2 *>(my + cfg.lds_off[c]);
+                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) dst[i] = make_uint2(B.img[i], 0);
+                else if (cc.type == ZT_ISSE)
+                    for (int i = li; i < 256; i += G) dst[i] = make_uint2(B.img[256 + 2 * i], B.img[257 + 2 * i]);
                 else if (cc.type == ZT_MIX2) {
                     u32 *w = reinterpret_cast<u32 *>(slot + cc.a16_off);
                     const u32 words = (cc.a16_len + 1) / 2;
@@ -270,159 +286,178 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         const u32 cap = (u32)(B.out_off[blk + 1] - B.out_off[blk]);
         i32 status = ZPQ_OK;
 
-        // ZPAQL state
         Vm z;
         z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0;
         z.m = slot + M.m_off; z.mlen = M.mlen;
         z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
         z.r = reinterpret_cast<u32 *>(slot + M.r_off);
         z.hdr = M.header; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
-        u32 prev = 0;          // VM_HASHCHAIN: M[b] of the next run (the byte stored by the previous run)
-        u32 m4 = 0, b4 = 0;    // VM_LEVEL1: the 4-byte M and B
-        u32 hctx = 0;          // this lane's H[li] (Predictor.h[li])
+        u32 prev = 0, m4 = 0, b4 = 0, hctx = 0;
 
-        // coder state (meaningful on lane `last`)
-        u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, ipos = 0;
+        BitCtx X;
+        X.low = 1; X.high = 0xFFFFFFFFu; X.code = 0; X.opos = 0; X.ipos = 0;
+        X.r0 = X.r1 = X.r2 = X.r3 = 0; X.slot = 1; X.c8 = 1;
         u32 first = 0xFFFFFFFFu;
         bool got_first = false;
         if (DEC) {
-            for (int k = 0; k < 4; k++) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+            for (int k = 0; k < 4; k++) { u32 c = 0; if (X.ipos < nin) c = src[X.ipos++]; X.code = (X.code << 8) | c; }
         }
         const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
+        u32 ch = 0;
+        u8 *raddr = ht;
+
+        // one bit: predict -> code -> update; all lanes run the same instruction stream
+        auto bitstep = [&](auto kc, const int bit) {
+            constexpr int K = decltype(kc)::value;
+            const u32 sh = (X.slot & 3u) * 8u;
+            const u32 dsel = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
+            const u32 s = (dsel >> sh) & 255u;
+            // ---- predict (predictor.v:555-563,615-631,667)
+            const uint2 e = tab[s];
+            const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);   // next state for y=0 | y=1 << 8
+            const u32 cmv = e.x;
+            u32 q = cmv >> 8;
+            q = q < 1u ? 1u : q;
+            const u32 wv = s_stretch[q >> 4];
+            const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+            const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+            const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+            const i32 p_icm = (q < 64u || q >= 32704u) ? endv : midv;
+            const i32 w0 = (i32)e.x, w1 = (i32)e.y;
+            i32 p = is_icm ? p_icm : 0, pin = 0;
+            for (int i = 1; i < cfg.nisse_end; i++) {
+                const i32 pv = row_shr1(p);
+                const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
+                const bool me = li == i;
+                pin = me ? pv : pin;
+                p = me ? pn : p;
+            }
+            i32 pj = 0, pk = 0, wmix = 0;
+            u32 mcx = 0;
+            if (cfg.has_mix2) {
+                pj = row_bcast(p, row_base + mix_j);
+                pk = row_bcast(p, row_base + mix_k);
+                if (is_last) {
+                    mcx = (hctx + (X.c8 & mix_mask)) & mix_cmask;
+                    wmix = a16[mcx];
+                    p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                }
+            }
+            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li])
+
+            // ---- code the bit on the lane that owns the final prediction
+            i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
+            if (is_last) {
+                const u32 p16 = (u32)sq * 2u + 1u;
+                const u32 mid = X.low + (u32)(((u64)(X.high - X.low) * p16) >> 16);
+                if (DEC) y = X.code <= mid ? 1 : 0;
+                X.high = y ? mid : X.high;
+                X.low = y ? X.low : mid + 1;
+                while ((X.high ^ X.low) < 0x1000000u) {
+                    if (!DEC) { if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24); X.opos++; }
+                    X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
+                    if (DEC) { u32 c = 0; if (X.ipos < nin) c = src[X.ipos++]; X.code = (X.code << 8) | c; }
+                }
+            }
+            if (DEC) y = row_bcast(y, row_base + last);
+
+            // ---- update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
+            const i32 t = y * 32767;
+            const u32 cm_new = (u32)wadd((i32)cmv, (t - (i32)(cmv >> 8)) >> 2);
+            const i32 err = t - sq;
+            const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
+            const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
+            tab[s] = make_uint2(is_icm ? cm_new : (u32)nw0, is_icm ? 0u : (u32)nw1);
+            if (cfg.has_mix2 && ctype == ZT_MIX2) {
+                const i32 em = wmul(t - sq, mix_rate) >> 5;
+                i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                w = min(max(w, 0), 65535);
+                a16[mcx] = (u16)w;
+            }
+            // next bit-history state into the row (statetable.v:75-84)
+            const u32 nsv = y ? (ns01 >> 8) : (ns01 & 255u);
+            const u32 ins = (dsel & ~(255u << sh)) | (nsv << sh);
+            if (K <= 1) X.r0 = ins;
+            else if (K == 2) X.r1 = ins;
+            else { X.r3 = (X.slot & 4u) ? ins : X.r3; X.r2 = (X.slot & 4u) ? X.r2 : ins; }
+            X.c8 = (X.c8 << 1) | (u32)y;
+            X.slot = (K == 3) ? 1u : (X.slot * 2u + (u32)y);
+        };
+
+        // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
+        auto find_row = [&]() {
+            if (hashed) {
+                const u32 cx = hctx + 16u * X.c8;
+                const u32 chk = (cx >> sizebits) & 255u;
+                const u32 h0 = (cx * 16u) & ht_mask;
+                u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
+                const u32x4 A = *reinterpret_cast<const u32x4 *>(pa);
+                const u32x4 Bq = *reinterpret_cast<const u32x4 *>(pb);
+                const u32x4 Cq = *reinterpret_cast<const u32x4 *>(pc);
+                const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
+                const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+                const bool va = qa <= qb && qa <= qc, vb = qb < qc;        // victim order (predictor.v:513-531)
+                const bool hit = ma || mb || mc;
+                const bool ua = ma || (!hit && va);
+                const bool ub = !ua && (mb || (!hit && vb));
+                raddr = ua ? pa : (ub ? pb : pc);
+                const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
+                X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
+            }
+        };
+        auto store_row = [&]() {
+            if (hashed) *reinterpret_cast<uint4 *>(raddr) = make_uint4(X.r0, X.r1, X.r2, X.r3);
+        };
 
         for (u32 bi = 0; bi < total; bi++) {
-            u32 ch = 0;
             if (!DEC) {
                 if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : src[bi - 1];
                 else ch = src[bi];
             }
             // ---- EOF flag: encode(0,0) / decode(0)  (encoder.v:108, decoder.v:128)
             if (!DEC) {
-                if (li == last) {
-                    low += 1;                               // p=0, y=0: mid = low, low = mid+1
-                    while ((high ^ low) < 0x1000000u) {
-                        if (opos < cap) dst[opos] = (u8)(high >> 24);
-                        opos++;
-                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                if (is_last) {
+                    X.low += 1;                               // p=0, y=0: mid = low, low = mid+1
+                    while ((X.high ^ X.low) < 0x1000000u) {
+                        if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24);
+                        X.opos++;
+                        X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
                     }
                 }
             } else {
                 i32 eof = 0;
-                if (li == last) {
-                    if (code <= low) { eof = 1; high = low; } else { low = low + 1; }   // p=0: mid = low
-                    while ((high ^ low) < 0x1000000u) {
-                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
-                        u32 c = 0; if (ipos < nin) c = src[ipos++];
-                        code = (code << 8) | c;
+                if (is_last) {
+                    if (X.code <= X.low) { eof = 1; X.high = X.low; } else { X.low = X.low + 1; }   // p=0: mid = low
+                    while ((X.high ^ X.low) < 0x1000000u) {
+                        X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
+                        u32 c = 0; if (X.ipos < nin) c = src[X.ipos++];
+                        X.code = (X.code << 8) | c;
                     }
                 }
                 eof = row_bcast(eof, row_base + last);
                 if (eof) break;
             }
 
-            u32 c8 = 1, slotn = 1;
-            uint4 R = make_uint4(0, 0, 0, 0);
-            u8 *raddr = ht;
-#pragma unroll 1
-            for (int bit = 7; bit >= 0; bit--) {
-                // ---- nibble start: find_ht (predictor.v:495-532) on every hashed lane
-                if ((bit & 3) == 3 && hashed) {
-                    const u32 cx = hctx + 16u * c8;
-                    const u32 chk = (cx >> sizebits) & 255u;
-                    const u32 h0 = (cx * 16u) & ht_mask;
-                    const uint4 A = *reinterpret_cast<const uint4 *>(ht + h0);
-                    const uint4 Bq = *reinterpret_cast<const uint4 *>(ht + (h0 ^ 16u));
-                    const uint4 Cq = *reinterpret_cast<const uint4 *>(ht + (h0 ^ 32u));
-                    if ((A.x & 255u) == chk) { R = A; raddr = ht + h0; }
-                    else if ((Bq.x & 255u) == chk) { R = Bq; raddr = ht + (h0 ^ 16u); }
-                    else if ((Cq.x & 255u) == chk) { R = Cq; raddr = ht + (h0 ^ 32u); }
-                    else {
-                        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
-                        if (qa <= qb && qa <= qc) raddr = ht + h0;
-                        else if (qb < qc) raddr = ht + (h0 ^ 16u);
-                        else raddr = ht + (h0 ^ 32u);
-                        R = make_uint4(chk, 0, 0, 0);
-                    }
-                }
-                // ---- predict (predictor.v:555-563,586-599,615-631,667)
-                const u32 s = row_byte(R, slotn);
-                i32 p = 0, w0 = 0, w1 = 0, pin = 0;
-                u32 cmv = 0, mcx = 0;
-                if (ctype == ZT_ICM) {
-                    cmv = cm32[s];
-                    u32 q = cmv >> 8;
-                    q = q < 1u ? 1u : q;                         // stretch(): idx<1 -> 1
-                    const u32 wv = s_stretch[q >> 4];
-                    const u32 k = q & 15u;
-                    i32 mid = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << k) - 1u) & 0xFFFEu);
-                    const u32 ei = q < 64u ? q : (q - 32704u + 64u);
-                    const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
-                    p = (q < 64u || q >= 32704u) ? endv : mid;
-                } else if (ctype == ZT_ISSE) {
-                    const uint2 wv = *reinterpret_cast<const uint2 *>(cm32 + s * 2);
-                    w0 = (i32)wv.x; w1 = (i32)wv.y;
-                }
-                for (int i = 1; i < cfg.nisse_end; i++) {
-                    const i32 pv = row_shr1(p);
-                    if (li == i) { pin = pv; p = clamp2k(wadd(wmul(w0, pv), wmul(w1, 64)) >> 16); }
-                }
-                i32 pj = 0, pk = 0, wmix = 0;
-                if (cfg.has_mix2) {
-                    pj = row_bcast(p, row_base + mix_j);
-                    pk = row_bcast(p, row_base + mix_k);
-                    if (li == last) {
-                        mcx = (hctx + (c8 & mix_mask)) & mix_cmask;
-                        wmix = a16[mcx];
-                        p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
-                    }
-                }
-                i32 sqi = wadd(p, 2047);
-                sqi = min(max(sqi, 0), 4093);
-                const i32 sq = s_squash[sqi];                // squash(p[li]) (predictor.v:193-202)
-
-                // ---- code the bit on lane `last` (encoder.v:48-89 / decoder.v:73-118)
-                i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
-                if (li == last) {
-                    const u32 p16 = (u32)sq * 2u + 1u;
-                    const u32 mid = low + (u32)(((u64)(high - low) * p16) >> 16);
-                    if (DEC) y = code <= mid ? 1 : 0;
-                    if (y) high = mid; else low = mid + 1;
-                    while ((high ^ low) < 0x1000000u) {
-                        if (!DEC) { if (opos < cap) dst[opos] = (u8)(high >> 24); opos++; }
-                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
-                        if (DEC) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
-                    }
-                }
-                if (DEC) y = row_bcast(y, row_base + last);
-
-                // ---- update (predictor.v:701-709,744-762,776-791)
-                if (ctype == ZT_ICM) {
-                    cm32[s] = (u32)wadd((i32)cmv, (y * 32767 - (i32)(cmv >> 8)) >> 2);
-                } else if (ctype == ZT_ISSE) {
-                    const i32 err = y * 32767 - sq;
-                    const i32 nw0 = clamp512k(wadd(w0, wadd(wmul(err, pin), 1 << 12) >> 13));
-                    const i32 nw1 = clamp512k(wadd(w1, (err + 16) >> 5));
-                    *reinterpret_cast<uint2 *>(cm32 + s * 2) = make_uint2((u32)nw0, (u32)nw1);
-                } else if (ctype == ZT_MIX2) {
-                    const i32 err = wmul(y * 32767 - sq, mix_rate) >> 5;
-                    i32 w = wadd(wmix, wadd(wmul(err, pj - pk), 1 << 12) >> 13);
-                    w = min(max(w, 0), 65535);
-                    a16[mcx] = (u16)w;
-                }
-                if (hashed) row_set(R, slotn, s_ns[s * 4 + y]);
-                // ---- bit context (predictor.v:807-823)
-                c8 = (c8 << 1) | (u32)y;
-                slotn = ((bit & 3) == 0) ? 1u : ((slotn * 2 + (u32)y) & 15u);
-                if ((bit & 3) == 0 && hashed) *reinterpret_cast<uint4 *>(raddr) = R;
-            }
-            const u32 byte = c8 - 256;
+            X.c8 = 1; X.slot = 1;
+            find_row();
+            bitstep(std::integral_constant<int, 0>{}, 7);
+            bitstep(std::integral_constant<int, 1>{}, 6);
+            bitstep(std::integral_constant<int, 2>{}, 5);
+            bitstep(std::integral_constant<int, 3>{}, 4);
+            store_row();
+            find_row();
+            bitstep(std::integral_constant<int, 0>{}, 3);
+            bitstep(std::integral_constant<int, 1>{}, 2);
+            bitstep(std::integral_constant<int, 2>{}, 1);
+            bitstep(std::integral_constant<int, 3>{}, 0);
+            store_row();
+            const u32 byte = X.c8 - 256;
 
             // ---- ZPAQL.run(byte) and h[] copy (predictor.v:809-816)
             if (cfg.vm_kind == VM_HASHCHAIN) {
                 // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
-                u32 a = byte;
-                u32 hv = 0;
-                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; if (k == li) hv = a; }
+                u32 a = byte, hv = 0;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
                 hctx = hv;
                 prev = byte;
             } else if (cfg.vm_kind == VM_LEVEL1) {
@@ -446,35 +481,35 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
                 else {
-                    if (li == last && opos < cap) dst[opos] = (u8)byte;
-                    opos++;                                   // uniform across the group when decoding
-                    if (opos > cap) break;
+                    if (is_last && X.opos < cap) dst[X.opos] = (u8)byte;
+                    X.opos++;                                 // uniform across the group when decoding
+                    if (X.opos > cap) break;
                 }
             }
         }
 
-        // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139) / EOF bookkeeping
-        if (!DEC && li == last) {
-            high = low;                                        // encode(1, 0): mid = low, high = mid
-            while ((high ^ low) < 0x1000000u) {
-                if (opos < cap) dst[opos] = (u8)(high >> 24);
-                opos++;
-                low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+        // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
+        if (!DEC && is_last) {
+            X.high = X.low;                                   // encode(1, 0): mid = low, high = mid
+            while ((X.high ^ X.low) < 0x1000000u) {
+                if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24);
+                X.opos++;
+                X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
             }
             for (int sft = 24; sft >= 0; sft -= 8) {
-                if (opos < cap) dst[opos] = (u8)(high >> sft);
-                opos++;
+                if (X.opos < cap) dst[X.opos] = (u8)(X.high >> sft);
+                X.opos++;
             }
         }
         const i32 st0 = row_bcast(status, row_base);           // VM status lives on lane 0
-        if (li == last) {
+        if (is_last) {
             i32 st = st0;
-            if (opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
-            B.out_len[blk] = opos;
+            if (X.opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
+            B.out_len[blk] = X.opos;
             B.status[blk] = st;
             if (DEC) {
-                if (B.consumed) B.consumed[blk] = ipos;
-                if (B.final_code) B.final_code[blk] = code;
+                if (B.consumed) B.consumed[blk] = X.ipos;
+                if (B.final_code) B.final_code[blk] = X.code;
                 if (B.first_byte) B.first_byte[blk] = first;
             }
         }
@@ -493,7 +528,7 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     cfg->n = M->n;
     int off = 0, i = 0;
     if (M->comp[0].type != ZT_ICM) return false;
-    cfg->lds_off[0] = (uint16_t)off; off += 1024;
+    cfg->lds_off[0] = (uint16_t)off; off += 2048;              // ICM as {cm, 0} pairs
     for (i = 1; i < M->n && M->comp[i].type == ZT_ISSE; i++) {
         if (M->comp[i].b != i - 1) return false;               // chain: ISSE i is fed by component i-1
         cfg->lds_off[i] = (uint16_t)off; off += 2048;
@@ -505,6 +540,7 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         cfg->has_mix2 = 1;
         cfg->lds_off[i] = 0;
     }
+    cfg->lds_trash = off; off += 2048;                         // scratch entries for lanes without a table
     cfg->lds_per_block = off;
     // recognise the shipped HCOMP programs (levels.v:73-87,126-141,...)
     cfg->vm_kind = zpqc::VM_GENERIC;
