@@ -1,0 +1,79 @@
+"""CPU tests of the product's host side: libzpaq_hip.so loads, exports every symbol
+include/zpaq_hip.h declares, builds models (no GPU needed), and FAILS LOUDLY without
+a GPU (no CPU fallback).  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import oracle_lib as O
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(zpq):
+    L = zpq.lib()
+    hdr = open(os.path.join(ROOT, "include", "zpaq_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(zpq_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "missing export: " + n
+
+
+def test_tables_match_oracle(zpq):
+    L = zpq.lib()
+    sq = (C.c_int32 * 4096)(); st = (C.c_int32 * 32768)()
+    assert L.zpq_tables(sq, st) == 0      # also runs the start-up fingerprint self-check
+    osq = (C.c_int32 * 4096)(); ost = (C.c_int32 * 32768)()
+    O.lib().zo_tables(osq, ost, None, None, None)
+    assert bytes(sq) == bytes(osq) and bytes(st) == bytes(ost)
+
+
+def test_level_headers_and_scan_match_oracle(zpq):
+    for lv in range(-1, 8):
+        assert zpq.level_header(lv) == O.level_header(lv)
+        h = zpq.level_header(lv)
+        assert zpq.scan_header(h) == O.scan_header(h)
+    # scanner quirks: opcode 63 skips 2 operand bytes, 255 only 1 (compressor.v:130-137)
+    for h in (bytes([1, 1, 0, 0, 0, 0, 63, 1, 2, 7, 0]), bytes([1, 1, 0, 0, 0, 0, 255, 9, 9, 0]), b"", b"\1\2"):
+        assert zpq.scan_header(h) == O.scan_header(h)
+
+
+def test_model_walk(zpq):
+    sizes = {1: 36, 2: 12, 3: 80, 4: 385, 5: 2052}
+    for lv, mib in sizes.items():
+        m = zpq.Model(level=lv)
+        assert m.has_fast_path and m.ncomp == {1: 2, 2: 3, 3: 5, 4: 7, 5: 9}[lv]
+        assert mib <= m.state_bytes / 2**20 < mib + 1.1
+    assert zpq.Model(level=0).ncomp == 0
+    from inputs import C4B
+    m = zpq.Model(header=C4B)
+    assert m.ncomp == 9 and not m.has_fast_path and m.offsets == (39, 40, 69)
+    with pytest.raises(zpq.ZpqError) as e:        # MIX with m == 0 (predictor.v:426 divides by m)
+        zpq.Model(header=bytes([1, 1, 0, 0, 1, 7, 4, 0, 0, 24, 255, 0, 56, 0]))
+    assert e.value.code == -5
+    with pytest.raises(zpq.ZpqError) as e:        # truncated component record
+        zpq.Model(header=bytes([1, 1, 0, 0, 1, 9, 4]), offsets=(8, 8, 8))
+    assert e.value.code == -3
+    with pytest.raises(zpq.ZpqError) as e:        # table too large
+        zpq.Model(header=bytes([1, 1, 0, 0, 1, 3, 40, 0, 56, 0]))
+    assert e.value.code == -4
+
+
+def test_no_gpu_means_loud_failure_not_fallback(zpq):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(zpq.ZpqError) as e:
+        zpq.Context(0)
+    assert e.value.code == -1
+    # nothing under the product tree may reference the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "zpaq-v_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in src and "zpaq_oracle" not in src and "zo_" not in src, f
