@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=4096, help="blocks per GPU (weak scaling)")
+    ap.add_argument("--blocks", type=int, default=8192, help="blocks per GPU (weak scaling; C5 = 65536 blocks over 8 GPUs)")
     ap.add_argument("--level", type=int, default=2)
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,13 +164,19 @@ def main():
         ratio = stats[0].item() / B_total
         A = ALG_BYTES_PER_INPUT_BYTE_L.get(a.level, 195) + ratio
         dom_ms, dom_name = (dec_ms[-1], "k_chain<decode>") if dec_ms[-1] >= enc_ms[-1] else (enc_ms[-1], "k_chain<encode>")
+        # PMC traffic was collected at 4096 blocks per launch; scale to this launch size
+        pmc_blocks = 4096
         launch_bytes = A * nb * size                          # algorithmic bytes one launch moves
         achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
+                pmc_blocks = pj.get("_blocks_per_launch", 4096)
+                if traffic is not None:
+                    traffic = int(traffic * nb / pmc_blocks)
             except Exception:
                 traffic = None
         res = {
@@ -178,7 +184,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "level %d (ICM16+ISSE16+ISSE16), %d x %d B blocks per GPU (C3), one segment per "
+            "config": {"workload": "level %d (ICM16+ISSE16+ISSE16), %d x %d B blocks per GPU (C5's per-GPU share of 65536 blocks over 8 GPUs), one segment per "
                                    "block, classes b mod 4 = zeros/uniform/markov-text/periodic (text blocks drawn "
                                    "from 64 distinct generated blocks)" % (a.level, nb, size),
                        "blocks_per_gpu": nb, "block_bytes": size, "level": a.level,

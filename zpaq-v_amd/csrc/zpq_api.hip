@@ -230,9 +230,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         int nwg = (a.nblocks + bpw - 1) / bpw;
         const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
         if (nwg > cap_wg) nwg = cap_wg;
-        if ((uint64_t)nwg * bpw > max_by_mem) nwg = (int)(max_by_mem / bpw);
-        if (nwg < 1) return ZPQ_E_NOMEM;
         nslots = nwg * bpw;
+        if ((uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;      // last workgroup partly idle
+        if (nslots > a.nblocks) nslots = a.nblocks;
+        nwg = (nslots + bpw - 1) / bpw;
         grid = nwg;
     } else {
         nslots = a.nblocks;

@@ -6,8 +6,8 @@
 // Mapping (gfx950, wave64):
 //   * one ZPAQ block = one GROUP of G=16 lanes (one DPP row); a wave carries 4
 //     blocks, a workgroup W waves.  Lane c of a group owns component c.
-//   * per block in LDS: ICM cm[256] (1 KiB) and each ISSE's weight pairs
-//     cm[512] (2 KiB).  Shared per workgroup in LDS: squash (i16[4096]), the
+//   * per block in LDS: ICM cm[256] (1 KiB) and each ISSE's 256 weight pairs packed
+//     to 20+20 bits (1.25 KiB): 3.5 KiB per level-2 block, 32 blocks per CU.  Shared per workgroup in LDS: squash (i16[4096]), the
 //     state table ns[1024] and a 8.5 KiB packing of the 64 KiB stretch table.
 //   * per block in HBM (its state slot): the hash tables (64*2^sizebits bytes per
 //     component), M/H for the ZPAQL VM, MIX2 weights.  A nibble's bit-history
@@ -22,6 +22,7 @@
 // All arithmetic is integer and reproduces V's 32-bit wrap/arithmetic-shift
 // semantics; results are bit-identical to zpq_generic.hip and the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -29,6 +30,15 @@
 
 #include "../../include/zpaq_hip.h"
 #include "zpq_common.h"
+
+// Measured on MI355X at two waves per SIMD (profiles/r01): the pipelined step wins for
+// encode (364 vs 373 ms), the plain one for decode (427 vs 456 ms).
+#ifndef ZPQ_CHAIN_SPEC_ENC
+#define ZPQ_CHAIN_SPEC_ENC 1
+#endif
+#ifndef ZPQ_CHAIN_SPEC_DEC
+#define ZPQ_CHAIN_SPEC_DEC 0
+#endif
 
 namespace zpqc {
 
@@ -59,8 +69,9 @@ struct Cfg {
     int32_t blocks_per_wg;
     int32_t lds_per_block;     // bytes
     int32_t vm_kind;
-    int32_t lds_trash;         // byte offset of the scratch table idle / MIX2 lanes read and write
-    uint16_t lds_off[G];       // byte offset of component c's table inside the block's LDS state
+    int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
+    uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
+    uint16_t lds_off8[G];      // ISSE c's u8 table (w1 bits 12..19); 0xFFFF = none
 };
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
@@ -211,7 +222,9 @@ struct BitCtx {
     u32 low, high, code, opos, ipos;
 };
 
-template <bool DEC>
+// SPEC = software-pipelined bit step (next bit's table entries fetched early, update
+// forwarded in registers); !SPEC = plain read-predict-update per bit (fewer instructions).
+template <bool DEC, bool SPEC>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const int row_base = lane & ~(G - 1);
     const int bslot = wave * BPW + grp;
     const int slot_id = blockIdx.x * cfg.blocks_per_wg + bslot;
-    const int nslots = gridDim.x * cfg.blocks_per_wg;
+    const int nslots = B.nslots;                       // may be less than gridDim.x * blocks_per_wg
     u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
     u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
 
@@ -250,14 +263,18 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     u8 *ht = slot + C.ht_off;
     const u32 ht_mask = C.ht_len - 16u;
     const int sizebits = C.a + 2;
-    // every lane owns a table of 8-byte entries: ICM {cm, 0}, ISSE {w0, w1}; idle and MIX2
-    // lanes point at a per-block scratch table so that no role branch is needed per bit
-    uint2 *tab = reinterpret_cast<uint2 *>(my + (hashed ? cfg.lds_off[li] : cfg.lds_trash));
+    // Packed per-block state: ICM cm[256] as u32; ISSE weights are 20-bit two's complement
+    // (clamp512k, predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.
+    // Lanes without a table (idle, MIX2, and the ICM's missing t8) use per-workgroup dummy
+    // tables, so the bit loop needs no role branches.
+    u8 *dummy = lds + LDS_STATE + cfg.lds_dummy;
+    u32 *t32 = reinterpret_cast<u32 *>(hashed ? my + cfg.lds_off32[li] : dummy);
+    u8 *t8 = is_isse ? my + cfg.lds_off8[li] : dummy + 1024;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const int mix_j = M.comp[last].j, mix_k = M.comp[last].k, mix_rate = M.comp[last].rate;
     const u32 mix_mask = (u32)M.comp[last].mask, mix_cmask = (u32)(M.comp[last].c - 1);
 
-    for (int blk = slot_id; blk < B.nblocks; blk += nslots) {
+    for (int blk = slot_id; slot_id < nslots && blk < B.nblocks; blk += nslots) {
         // ---- Predictor.init + ZPAQL.clear for this block (predictor.v:325-470, zpaql.v:54-95)
         {
             uint4 *z4 = reinterpret_cast<uint4 *>(slot);
@@ -266,10 +283,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             for (u64 i = li; i < n16; i += G) z4[i] = zero;
             for (int c = 0; c < n; c++) {
                 const DComp &cc = M.comp[c];
-                uint2 *dst = reinterpret_cast<uint2 *>(my + cfg.lds_off[c]);
-                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) dst[i] = make_uint2(B.img[i], 0);
-                else if (cc.type == ZT_ISSE)
-                    for (int i = li; i < 256; i += G) dst[i] = make_uint2(B.img[256 + 2 * i], B.img[257 + 2 * i]);
+                u32 *d32 = reinterpret_cast<u32 *>(my + cfg.lds_off32[c]);
+                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) d32[i] = B.img[i];
+                else if (cc.type == ZT_ISSE) {
+                    u8 *d8 = my + cfg.lds_off8[c];
+                    for (int i = li; i < 256; i += G) {
+                        const u32 a0 = B.img[256 + 2 * i], a1 = B.img[257 + 2 * i];
+                        d32[i] = (a0 & 0xFFFFFu) | (a1 << 20);
+                        d8[i] = (u8)((i32)a1 >> 12);
+                    }
+                }
                 else if (cc.type == ZT_MIX2) {
                     u32 *w = reinterpret_cast<u32 *>(slot + cc.a16_off);
                     const u32 words = (cc.a16_len + 1) / 2;
@@ -294,37 +317,102 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         z.hdr = M.header; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
         u32 prev = 0, m4 = 0, b4 = 0, hctx = 0;
 
+        // Input window: the next bytes of `src` live in two registers, refilled by aligned
+        // dword loads issued a whole dword ahead of use (never a load on the bit path).
+        // Virtual position vp = byte index + (src & 3); dword k covers vp 4k..4k+3.
+        const u32 mis = (u32)(reinterpret_cast<uintptr_t>(src) & 3u);
+        const u32 *src4 = reinterpret_cast<const u32 *>(src - mis);
+        const u32 ndw = (nin + mis + 3u) >> 2;              // dwords that hold at least one valid byte
+        u32 win0 = ndw > 0 ? src4[0] : 0u, win1 = ndw > 1 ? src4[1] : 0u;
+        u32 wdw = 0;                                       // dword index held in win0
+        auto in_byte = [&](u32 pos) -> u32 {               // src[pos] for pos in the current/next dword; 0 past the end
+            const u32 vp = pos + mis;
+            if ((vp >> 2) != wdw) {                        // crossed into win1: slide and prefetch one more dword
+                win0 = win1;
+                wdw++;
+                win1 = (wdw + 1 < ndw) ? src4[wdw + 1] : 0u;
+            }
+            const u32 c = (win0 >> ((vp & 3u) * 8u)) & 255u;
+            return pos < nin ? c : 0u;
+        };
+
         BitCtx X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.code = 0; X.opos = 0; X.ipos = 0;
         X.r0 = X.r1 = X.r2 = X.r3 = 0; X.slot = 1; X.c8 = 1;
         u32 first = 0xFFFFFFFFu;
         bool got_first = false;
         if (DEC) {
-            for (int k = 0; k < 4; k++) { u32 c = 0; if (X.ipos < nin) c = src[X.ipos++]; X.code = (X.code << 8) | c; }
+            for (int k = 0; k < 4; k++) { const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c; }
         }
         const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
         u32 ch = 0;
         u8 *raddr = ht;
 
-        // one bit: predict -> code -> update; all lanes run the same instruction stream
-        auto bitstep = [&](auto kc, const int bit) {
-            constexpr int K = decltype(kc)::value;
-            const u32 sh = (X.slot & 3u) * 8u;
-            const u32 dsel = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
-            const u32 s = (dsel >> sh) & 255u;
-            // ---- predict (predictor.v:555-563,615-631,667)
-            const uint2 e = tab[s];
-            const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);   // next state for y=0 | y=1 << 8
-            const u32 cmv = e.x;
-            u32 q = cmv >> 8;
-            q = q < 1u ? 1u : q;
+        // stretch(cm >> 8) from the 8.5 KiB LDS packing (predictor.v:205-214); `cm` may be any u32
+        auto stretch_lds = [&](u32 cm) -> i32 {
+            u32 q = cm >> 8;
+            q = min(max(q, 1u), 32767u);
             const u32 wv = s_stretch[q >> 4];
             const u32 ei = q < 64u ? q : (q - 32704u + 64u);
             const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
             const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
-            const i32 p_icm = (q < 64u || q >= 32704u) ? endv : midv;
-            const i32 w0 = (i32)e.x, w1 = (i32)e.y;
-            i32 p = is_icm ? p_icm : 0, pin = 0;
+            return (q < 64u || q >= 32704u) ? endv : midv;
+        };
+        // decoded bit from lane `last` to the lanes below it: log-step DPP row_shl, no LDS round trip
+        const int bdist = last - li;                       // > 0 on lanes that need the value
+        auto bcast_down = [&](i32 v) -> i32 {
+            if (n > 1) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x101 /*row_shl:1*/, 0xf, 0xf, false); v = (bdist == 1) ? t : v; }
+            if (n > 2) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x102 /*row_shl:2*/, 0xf, 0xf, false); v = (bdist >= 2 && bdist < 4) ? t : v; }
+            if (n > 4) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0xf, false); v = (bdist >= 4 && bdist < 8) ? t : v; }
+            if (n > 8) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x108 /*row_shl:8*/, 0xf, 0xf, false); v = (bdist >= 8) ? t : v; }
+            return v;
+        };
+
+        // Software-pipelined bit step.  Carried between steps: the current state byte, its
+        // table entry with the previous bit's update already forwarded, and (ICM) its stretch.
+        u32 cur_s = 0, cur_v = 0;                          // state byte, packed entry (forwarded)
+        i32 cur_b = 0, cur_pst = 0;                        // w1's top byte, ICM stretch
+
+        auto nibble_begin = [&]() {                        // after find_row: slot 1 = byte 1 of the row
+            cur_s = (X.r0 >> 8) & 255u;
+            cur_v = t32[cur_s];
+            cur_b = (i32)(int8_t)t8[cur_s];
+            cur_pst = stretch_lds(cur_v);
+        };
+
+        auto bitstep = [&](auto kc, const int bit) {
+            constexpr int K = decltype(kc)::value;
+            if (!SPEC && K > 0) {                              // plain form: this bit's state from the row
+                const u32 shp = (X.slot & 3u) * 8u;
+                const u32 dp = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
+                cur_s = (dp >> shp) & 255u;
+                cur_v = t32[cur_s];
+                cur_b = (i32)(int8_t)t8[cur_s];
+                cur_pst = stretch_lds(cur_v);
+            }
+            const u32 s = cur_s;
+            const i32 yk = DEC ? 0 : (i32)((ch >> bit) & 1u);  // encode knows its bit up front
+            // ---- (1) next bit's candidate states and their table entries, read BEFORE this
+            //          bit's update is stored; slots 2*slot and 2*slot+1 are adjacent row bytes
+            u32 sA = 0, sB = 0;
+            u32 rAv = 0, rBv = 0;
+            i32 rAb = 0, rBb = 0;
+            if (SPEC && K < 3) {
+                u32 pair;
+                if (K == 0) pair = X.r0 >> 16;
+                else if (K == 1) pair = X.r1 >> ((X.slot & 1u) * 16u);
+                else pair = ((X.slot & 2u) ? X.r3 : X.r2) >> ((X.slot & 1u) * 16u);
+                sA = pair & 255u;
+                sB = (pair >> 8) & 255u;
+                if (DEC) { rAv = t32[sA]; rBv = t32[sB]; rAb = (i32)(int8_t)t8[sA]; rBb = (i32)(int8_t)t8[sB]; }
+                else { sA = yk ? sB : sA; rAv = t32[sA]; rAb = (i32)(int8_t)t8[sA]; }
+            }
+            const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);   // next state for y=0 | y=1 << 8
+            // ---- (2) predict: chain p0 -> p1 -> ... (predictor.v:555-563,615-631)
+            const u32 cmv = cur_v;                                               // ICM lanes
+            const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE lanes: sext20
+            const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
+            i32 p = is_icm ? cur_pst : 0, pin = 0;
             for (int i = 1; i < cfg.nisse_end; i++) {
                 const i32 pv = row_shr1(p);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
@@ -343,10 +431,22 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
                 }
             }
-            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li])
-
-            // ---- code the bit on the lane that owns the final prediction
-            i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
+            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li]) (predictor.v:193-202,667)
+            // ---- (3) off the critical path: the ICM's stretch for the next bit, for both
+            //          outcomes, with this bit's cm update forwarded when the state repeats
+            const u32 cm0 = (u32)wadd((i32)cmv, (0 - (i32)(cmv >> 8)) >> 2);       // y = 0 (predictor.v:706-708)
+            const u32 cm1 = (u32)wadd((i32)cmv, (32767 - (i32)(cmv >> 8)) >> 2);   // y = 1
+            i32 stA = 0, stB = 0;
+            if (SPEC && K < 3) {
+                if (DEC) {
+                    stA = stretch_lds(sA == s ? cm0 : rAv);
+                    stB = stretch_lds(sB == s ? cm1 : rBv);
+                } else {
+                    stA = stretch_lds(sA == s ? (yk ? cm1 : cm0) : rAv);
+                }
+            }
+            // ---- (4) code the bit on the lane that owns the final prediction
+            i32 y = yk;
             if (is_last) {
                 const u32 p16 = (u32)sq * 2u + 1u;
                 const u32 mid = X.low + (u32)(((u64)(X.high - X.low) * p16) >> 16);
@@ -356,26 +456,39 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 while ((X.high ^ X.low) < 0x1000000u) {
                     if (!DEC) { if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24); X.opos++; }
                     X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
-                    if (DEC) { u32 c = 0; if (X.ipos < nin) c = src[X.ipos++]; X.code = (X.code << 8) | c; }
+                    if (DEC) { const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c; }
                 }
             }
-            if (DEC) y = row_bcast(y, row_base + last);
-
-            // ---- update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
-            const i32 t = y * 32767;
-            const u32 cm_new = (u32)wadd((i32)cmv, (t - (i32)(cmv >> 8)) >> 2);
-            const i32 err = t - sq;
+            if (DEC) y = bcast_down(y);
+            // ---- (5) update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
+            const i32 err = y * 32767 - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-            tab[s] = make_uint2(is_icm ? cm_new : (u32)nw0, is_icm ? 0u : (u32)nw1);
+            const u32 nv = is_icm ? (y ? cm1 : cm0) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
+            const i32 nb = nw1 >> 12;
+            t32[s] = nv;
+            t8[s] = (u8)nb;
             if (cfg.has_mix2 && ctype == ZT_MIX2) {
-                const i32 em = wmul(t - sq, mix_rate) >> 5;
+                const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
                 a16[mcx] = (u16)w;
             }
+            // ---- (6) hand the next bit its state, forwarded entry and stretch
+            if (SPEC && K < 3) {
+                const u32 sn = DEC ? (y ? sB : sA) : sA;
+                const u32 rv = DEC ? (y ? rBv : rAv) : rAv;
+                const i32 rb = DEC ? (y ? rBb : rAb) : rAb;
+                const bool same = sn == s;
+                cur_v = same ? nv : rv;
+                cur_b = same ? nb : rb;
+                cur_pst = DEC ? (y ? stB : stA) : stA;
+                cur_s = sn;
+            }
             // next bit-history state into the row (statetable.v:75-84)
             const u32 nsv = y ? (ns01 >> 8) : (ns01 & 255u);
+            const u32 sh = (X.slot & 3u) * 8u;
+            const u32 dsel = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
             const u32 ins = (dsel & ~(255u << sh)) | (nsv << sh);
             if (K <= 1) X.r0 = ins;
             else if (K == 2) X.r1 = ins;
@@ -411,8 +524,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
         for (u32 bi = 0; bi < total; bi++) {
             if (!DEC) {
-                if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : src[bi - 1];
-                else ch = src[bi];
+                if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : in_byte(bi - 1);
+                else ch = in_byte(bi);
             }
             // ---- EOF flag: encode(0,0) / decode(0)  (encoder.v:108, decoder.v:128)
             if (!DEC) {
@@ -430,7 +543,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     if (X.code <= X.low) { eof = 1; X.high = X.low; } else { X.low = X.low + 1; }   // p=0: mid = low
                     while ((X.high ^ X.low) < 0x1000000u) {
                         X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
-                        u32 c = 0; if (X.ipos < nin) c = src[X.ipos++];
+                        const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin);
                         X.code = (X.code << 8) | c;
                     }
                 }
@@ -440,12 +553,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
             X.c8 = 1; X.slot = 1;
             find_row();
+            nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 7);
             bitstep(std::integral_constant<int, 1>{}, 6);
             bitstep(std::integral_constant<int, 2>{}, 5);
             bitstep(std::integral_constant<int, 3>{}, 4);
             store_row();
             find_row();
+            nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 3);
             bitstep(std::integral_constant<int, 1>{}, 2);
             bitstep(std::integral_constant<int, 2>{}, 1);
@@ -528,19 +643,20 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     cfg->n = M->n;
     int off = 0, i = 0;
     if (M->comp[0].type != ZT_ICM) return false;
-    cfg->lds_off[0] = (uint16_t)off; off += 2048;              // ICM as {cm, 0} pairs
+    for (int c = 0; c < zpqc::G; c++) cfg->lds_off8[c] = 0xFFFF;
+    cfg->lds_off32[0] = (uint16_t)off; off += 1024;
     for (i = 1; i < M->n && M->comp[i].type == ZT_ISSE; i++) {
         if (M->comp[i].b != i - 1) return false;               // chain: ISSE i is fed by component i-1
-        cfg->lds_off[i] = (uint16_t)off; off += 2048;
+        cfg->lds_off32[i] = (uint16_t)off; off += 1024;
+        cfg->lds_off8[i] = (uint16_t)off; off += 256;
     }
     cfg->nisse_end = i;
     if (i < M->n) {
         if (i != M->n - 1 || M->comp[i].type != ZT_MIX2) return false;
         if (M->comp[i].j >= i || M->comp[i].k >= i) return false;
         cfg->has_mix2 = 1;
-        cfg->lds_off[i] = 0;
+        cfg->lds_off32[i] = 0;
     }
-    cfg->lds_trash = off; off += 2048;                         // scratch entries for lanes without a table
     cfg->lds_per_block = off;
     // recognise the shipped HCOMP programs (levels.v:73-87,126-141,...)
     cfg->vm_kind = zpqc::VM_GENERIC;
@@ -557,13 +673,12 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         if (plen == (int)sizeof l1 && memcmp(p, l1, sizeof l1) == 0 && M->mlen == 4 && M->hlen == 2 && M->n == 2)
             cfg->vm_kind = zpqc::VM_LEVEL1;
     }
-    const int avail = 160 * 1024 - zpqc::LDS_STATE - 256;
+    const int avail = 160 * 1024 - zpqc::LDS_STATE - 1280 /*dummy tables*/ - 256;
     int bpw = avail / cfg->lds_per_block;
-    if (bpw > zpqc::MAXW * zpqc::BPW) bpw = zpqc::MAXW * zpqc::BPW;
+    if (bpw > zpqc::MAXW * zpqc::BPW) bpw = zpqc::MAXW * zpqc::BPW;   // <= 8 waves: two per SIMD
     bpw = bpw / zpqc::BPW * zpqc::BPW;
-    // 16 blocks per workgroup (4 waves, one per SIMD) unless the model's LDS state is bigger
-    if (bpw > 16) bpw = 16;
     if (bpw < zpqc::BPW) return false;
+    cfg->lds_dummy = bpw * cfg->lds_per_block;
     cfg->blocks_per_wg = bpw;
     return true;
 }
@@ -590,14 +705,23 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     Cfg cfg;
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     const int threads = cfg.blocks_per_wg / zpqc::BPW * 64;
-    const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block;
+    const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (decode) hipLaunchKernelGGL(zpqc::k_chain<true>, dim3(nwg), dim3(threads), lds, stream, *B, cfg);
-    else hipLaunchKernelGGL(zpqc::k_chain<false>, dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+    const char *ev = getenv("ZPQ_CHAIN_SPEC");            // tuning knob: 0 = plain, 1 = pipelined bit step
+    const int spec = ev ? atoi(ev) : (decode ? ZPQ_CHAIN_SPEC_DEC : ZPQ_CHAIN_SPEC_ENC);
+    if (decode) {
+        if (spec) hipLaunchKernelGGL((zpqc::k_chain<true, true>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+        else hipLaunchKernelGGL((zpqc::k_chain<true, false>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+    } else {
+        if (spec) hipLaunchKernelGGL((zpqc::k_chain<false, true>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+        else hipLaunchKernelGGL((zpqc::k_chain<false, false>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+    }
     return ZPQ_OK;
 }
