@@ -1,0 +1,177 @@
+// zpaq_frontend.hpp -- C++ mirror of the reference's block/segment front end
+// (zpaq/compressor.v, zpaq/decompressor.v, zpaq/io.v) on top of the C ABI in
+// zpaq_hip.h.  Same method names, argument meaning, call order and the same silent
+// state-machine guards (compressor.v:80,213,260,358,403); the per-byte coder calls are
+// replaced by one zpq_block_* call per segment.  Framing (block locator, header,
+// segment header/trailer, SHA-1, store mode) is done on the host and is byte-identical
+// to the reference's writer.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "zpaq_hip.h"
+
+namespace zpaq {
+
+// io.v:6-21
+struct Reader {
+    virtual ~Reader() {}
+    virtual int get() = 0;                       // one byte, -1 at EOF
+    virtual int read(uint8_t *buf, int n);       // default: loop over get()
+};
+struct Writer {
+    virtual ~Writer() {}
+    virtual void put(int c) = 0;
+    virtual void write(const uint8_t *buf, int n);
+};
+
+// io.v:40-108
+class FileReader : public Reader {
+public:
+    explicit FileReader(std::vector<uint8_t> data) : data_(std::move(data)), pos_(0) {}
+    int get() override { return pos_ < data_.size() ? data_[pos_++] : -1; }
+    size_t position() const { return pos_; }
+private:
+    std::vector<uint8_t> data_;
+    size_t pos_;
+};
+class FileWriter : public Writer {
+public:
+    void put(int c) override { data_.push_back((uint8_t)c); }
+    const std::vector<uint8_t> &bytes() const { return data_; }
+private:
+    std::vector<uint8_t> data_;
+};
+
+// sha1.v:6-146
+class SHA1 {
+public:
+    SHA1() { init(); }
+    void init();
+    void put(int c);
+    void write_bytes(const uint8_t *p, size_t n);
+    std::vector<uint8_t> result();
+private:
+    void process_block();
+    uint64_t len0_;
+    uint32_t h_[5];
+    uint8_t buf_[64];
+    int bufn_;
+    bool final_;
+};
+
+// compressor.v:16-418
+class Compressor {
+public:
+    explicit Compressor(zpq_ctx *ctx);           // Compressor.new(); ctx may be null for store mode only
+    ~Compressor();
+    void set_input(Reader *r) { input_ = r; }
+    void set_output(Writer *w) { output_ = w; }
+    void start_block(int level);                                   // compressor.v:79-188
+    void start_block_hcomp(const std::string &hcomp);              // compressor.v:191-209 (quirk Q14 kept)
+    void start_segment(const std::string &filename, const std::string &comment);   // :212-255
+    bool compress(int n);                                          // :259-293  true iff n bytes were read
+    void end_segment();                                            // :357-399
+    void end_block();                                              // :402-413
+    std::vector<uint8_t> get_sha1() { return sha1_.result(); }     // :416-418
+    int last_error() const { return err_; }                        // ZPQ_* of the last GPU call (the reference has none)
+private:
+    bool compress_store(int n);
+    void flush_store_buffer();
+    void drop_block();
+    enum { kBlock = 0, kSegment = 1, kStart = 2 };
+    int state_;
+    zpq_ctx *ctx_;
+    zpq_model *model_;
+    zpq_block *block_;
+    Reader *input_;
+    Writer *output_;
+    SHA1 sha1_;
+    int level_;
+    int ncomp_;
+    std::vector<uint8_t> header_;
+    std::vector<uint8_t> stage_;       // bytes of the open segment awaiting the coder
+    bool pp_coded_;                    // compress() ran at least once: PP byte goes first (:271-274)
+    std::vector<uint8_t> store_buf_;
+    bool first_byte_;
+    int err_;
+};
+
+// decompressor.v:169-640
+class Decompresser {
+public:
+    explicit Decompresser(zpq_ctx *ctx);
+    ~Decompresser();
+    void set_input(Reader *r);
+    void set_output(Writer *w) { output_ = w; }
+    bool find_block();                                             // decompressor.v:219-346
+    bool find_filename();                                          // :350-429
+    std::string get_filename() const { return filename_; }
+    std::string get_comment() const { return comment_; }
+    bool decompress(int n);                                        // :443-515  n < 0 = all
+    void read_segment_end();                                       // :590-635
+    std::vector<uint8_t> get_sha1() { return sha1_.result(); }
+    int last_error() const { return err_; }
+private:
+    int get();
+    bool decompress_store(int n);
+    bool decode_segment();
+    void drop_block();
+    enum { kBlock = 0, kSegment = 1, kFilename = 2, kStart = 3 };
+    int state_;
+    zpq_ctx *ctx_;
+    zpq_model *model_;
+    zpq_block *block_;
+    Reader *input_;
+    Writer *output_;
+    std::vector<uint8_t> in_;          // the Reader's bytes, pulled once (the coder needs a flat buffer)
+    size_t pos_;
+    bool slurped_;
+    SHA1 sha1_;
+    std::string filename_, comment_;
+    int ncomp_;
+    uint32_t store_count_;
+    bool first_seg_;
+    // decoded segment
+    bool decoded_;
+    std::vector<uint8_t> seg_;         // decoded bytes after the PP byte
+    size_t seg_pos_;
+    bool seg_empty_;                   // the coder hit EOF before any byte (compress() never called)
+    uint32_t final_code_;
+    int segs_in_block_;
+    int err_;
+};
+
+}  // namespace zpaq
+
+// Flat C surface over the two classes (in-memory Reader/Writer), used by the ctypes tests.
+struct zpqf_comp;
+struct zpqf_decomp;
+extern "C" {
+zpqf_comp *zpqf_compressor_new(zpq_ctx *ctx);
+void zpqf_compressor_free(zpqf_comp *);
+void zpqf_compressor_set_input(zpqf_comp *, const uint8_t *p, size_t n);
+void zpqf_compressor_start_block(zpqf_comp *, int level);
+void zpqf_compressor_start_block_hcomp(zpqf_comp *, const uint8_t *p, size_t n);
+void zpqf_compressor_start_segment(zpqf_comp *, const char *filename, const char *comment);
+int zpqf_compressor_compress(zpqf_comp *, int n);
+void zpqf_compressor_end_segment(zpqf_comp *);
+void zpqf_compressor_end_block(zpqf_comp *);
+int zpqf_compressor_last_error(zpqf_comp *);
+size_t zpqf_compressor_output(zpqf_comp *, const uint8_t **p);
+void zpqf_compressor_sha1(zpqf_comp *, uint8_t out20[20]);
+zpqf_decomp *zpqf_decompresser_new(zpq_ctx *ctx);
+void zpqf_decompresser_free(zpqf_decomp *);
+void zpqf_decompresser_set_input(zpqf_decomp *, const uint8_t *p, size_t n);
+int zpqf_decompresser_find_block(zpqf_decomp *);
+int zpqf_decompresser_find_filename(zpqf_decomp *);
+size_t zpqf_decompresser_filename(zpqf_decomp *, char *buf, size_t cap);
+size_t zpqf_decompresser_comment(zpqf_decomp *, char *buf, size_t cap);
+int zpqf_decompresser_decompress(zpqf_decomp *, int n);
+void zpqf_decompresser_read_segment_end(zpqf_decomp *);
+int zpqf_decompresser_last_error(zpqf_decomp *);
+size_t zpqf_decompresser_output(zpqf_decomp *, const uint8_t **p);
+void zpqf_decompresser_sha1(zpqf_decomp *, uint8_t out20[20]);
+}

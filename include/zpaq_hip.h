@@ -47,6 +47,8 @@ extern "C" {
                                  decode: drop the first decoded byte (the PP byte) from the output
                                  and report it in first_byte[] (decompressor.v:469-475). */
 #define ZPQ_FLAG_GENERIC 2u   /* force the generic all-component interpreter kernel */
+#define ZPQ_FLAG_NOEOF 4u     /* encode: stop after the last data byte, no compress(-1)/flush().  Only the
+                                 reference's component-less end_segment path needs it (compressor.v:364). */
 
 /* ---- header helpers: levels.v:26-375 (get_compression_level) and the scan
  *      that defines cend/hbegin/hend, compressor.v:96-145 ---- */

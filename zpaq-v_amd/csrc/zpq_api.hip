@@ -210,7 +210,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (rc != ZPQ_OK) return rc;
 
     const DModel &M = m->d;
-    const bool want_chain = M.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZB_CTX_ONLY)) && !a.trace &&
+    const bool want_chain = M.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) && !a.trace &&
                             zpq_chain_blocks_per_wg(&M) > 0;
     DBatch B;
     memset(&B, 0, sizeof B);

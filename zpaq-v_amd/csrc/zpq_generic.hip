@@ -585,7 +585,6 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
         u8 *dst = B.out + B.out_off[blk];
         const u32 cap = (u32)(B.out_off[blk + 1] - B.out_off[blk]);
         i32 st = ZPQ_OK;
-        const bool has_mix = true;   // MIX components need the wave converged in predict/update
 
         if (B.flags & ZB_CTX_ONLY) {
             if (lane == 0) {
@@ -617,10 +616,12 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
                 }
             }
             if (lane == 0) {
-                enc_bit(e, 1, 0);                               // compress(-1) (encoder.v:101-105)
-                for (int s = 24; s >= 0; s -= 8) {              // flush() (encoder.v:130-139)
-                    if (e.pos < e.cap) e.out[e.pos] = (u8)(e.high >> s);
-                    e.pos++;
+                if (!(B.flags & ZPQ_FLAG_NOEOF)) {
+                    enc_bit(e, 1, 0);                           // compress(-1) (encoder.v:101-105)
+                    for (int s = 24; s >= 0; s -= 8) {          // flush() (encoder.v:130-139)
+                        if (e.pos < e.cap) e.out[e.pos] = (u8)(e.high >> s);
+                        e.pos++;
+                    }
                 }
                 if (e.pos > e.cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
                 B.out_len[blk] = e.pos;
@@ -662,7 +663,6 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
                 B.status[blk] = st;
             }
         }
-        (void)has_mix;
         __syncthreads();
         // persist what outlives a segment
         if (lane == 0) { gr->a = z.a; gr->b = z.b; gr->c = z.c; gr->d = z.d; gr->f = z.f; gr->pc = z.pc; }

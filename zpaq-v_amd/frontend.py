@@ -1,0 +1,150 @@
+"""Python handles on the C++ front end (include/zpaq_frontend.hpp): Compressor and
+Decompresser with the reference's method names and call order
+(zpaq/compressor.v:33-418, zpaq/decompressor.v:187-640).  All work happens in
+libzpaq_hip.so; these classes only marshal arguments."""
+import ctypes as C
+
+from . import binding as B
+
+
+def _lib():
+    L = B.lib()
+    if getattr(L, "_zpqf_ready", False):
+        return L
+    vp, u8p = C.c_void_p, C.c_char_p
+    L.zpqf_compressor_new.restype = vp
+    L.zpqf_compressor_new.argtypes = [vp]
+    L.zpqf_compressor_free.argtypes = [vp]
+    L.zpqf_compressor_set_input.argtypes = [vp, u8p, C.c_size_t]
+    L.zpqf_compressor_start_block.argtypes = [vp, C.c_int]
+    L.zpqf_compressor_start_block_hcomp.argtypes = [vp, u8p, C.c_size_t]
+    L.zpqf_compressor_start_segment.argtypes = [vp, u8p, u8p]
+    L.zpqf_compressor_compress.argtypes = [vp, C.c_int]
+    L.zpqf_compressor_end_segment.argtypes = [vp]
+    L.zpqf_compressor_end_block.argtypes = [vp]
+    L.zpqf_compressor_last_error.argtypes = [vp]
+    L.zpqf_compressor_output.restype = C.c_size_t
+    L.zpqf_compressor_output.argtypes = [vp, vp]
+    L.zpqf_compressor_sha1.argtypes = [vp, vp]
+    L.zpqf_decompresser_new.restype = vp
+    L.zpqf_decompresser_new.argtypes = [vp]
+    L.zpqf_decompresser_free.argtypes = [vp]
+    L.zpqf_decompresser_set_input.argtypes = [vp, u8p, C.c_size_t]
+    L.zpqf_decompresser_find_block.argtypes = [vp]
+    L.zpqf_decompresser_find_filename.argtypes = [vp]
+    L.zpqf_decompresser_filename.restype = C.c_size_t
+    L.zpqf_decompresser_filename.argtypes = [vp, vp, C.c_size_t]
+    L.zpqf_decompresser_comment.restype = C.c_size_t
+    L.zpqf_decompresser_comment.argtypes = [vp, vp, C.c_size_t]
+    L.zpqf_decompresser_decompress.argtypes = [vp, C.c_int]
+    L.zpqf_decompresser_read_segment_end.argtypes = [vp]
+    L.zpqf_decompresser_last_error.argtypes = [vp]
+    L.zpqf_decompresser_output.restype = C.c_size_t
+    L.zpqf_decompresser_output.argtypes = [vp, vp]
+    L.zpqf_decompresser_sha1.argtypes = [vp, vp]
+    L._zpqf_ready = True
+    return L
+
+
+class Compressor:
+    """Compressor.new() (compressor.v:33-46).  `ctx` may be None for store mode (level 0)."""
+
+    def __init__(self, ctx=None):
+        self._L = _lib()
+        self.h = self._L.zpqf_compressor_new(ctx.h if ctx is not None else None)
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None) and B._LIB is not None:
+            self._L.zpqf_compressor_free(self.h)
+            self.h = None
+
+    def set_input(self, data):
+        self._keep = bytes(data)
+        self._L.zpqf_compressor_set_input(self.h, self._keep, len(self._keep))
+
+    def start_block(self, level):
+        self._L.zpqf_compressor_start_block(self.h, level)
+
+    def start_block_hcomp(self, hcomp):
+        self._L.zpqf_compressor_start_block_hcomp(self.h, bytes(hcomp), len(hcomp))
+
+    def start_segment(self, filename, comment):
+        self._L.zpqf_compressor_start_segment(self.h, filename.encode(), comment.encode())
+
+    def compress(self, n):
+        return bool(self._L.zpqf_compressor_compress(self.h, n))
+
+    def end_segment(self):
+        self._L.zpqf_compressor_end_segment(self.h)
+
+    def end_block(self):
+        self._L.zpqf_compressor_end_block(self.h)
+
+    @property
+    def last_error(self):
+        return self._L.zpqf_compressor_last_error(self.h)
+
+    def output_bytes(self):
+        p = C.c_void_p()
+        n = self._L.zpqf_compressor_output(self.h, C.byref(p))
+        return C.string_at(p, n) if n else b""
+
+    def get_sha1(self):
+        out = C.create_string_buffer(20)
+        self._L.zpqf_compressor_sha1(self.h, out)
+        return out.raw
+
+
+class Decompresser:
+    """Decompresser.new() (decompressor.v:187-200)."""
+
+    def __init__(self, ctx=None):
+        self._L = _lib()
+        self.h = self._L.zpqf_decompresser_new(ctx.h if ctx is not None else None)
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None) and B._LIB is not None:
+            self._L.zpqf_decompresser_free(self.h)
+            self.h = None
+
+    def set_input(self, data):
+        self._keep = bytes(data)
+        self._L.zpqf_decompresser_set_input(self.h, self._keep, len(self._keep))
+
+    def find_block(self):
+        return bool(self._L.zpqf_decompresser_find_block(self.h))
+
+    def find_filename(self):
+        return bool(self._L.zpqf_decompresser_find_filename(self.h))
+
+    def get_filename(self):
+        buf = C.create_string_buffer(4096)
+        self._L.zpqf_decompresser_filename(self.h, buf, 4096)
+        return buf.value.decode(errors="replace")
+
+    def get_comment(self):
+        buf = C.create_string_buffer(4096)
+        self._L.zpqf_decompresser_comment(self.h, buf, 4096)
+        return buf.value.decode(errors="replace")
+
+    def decompress(self, n):
+        return bool(self._L.zpqf_decompresser_decompress(self.h, n))
+
+    def read_segment_end(self):
+        self._L.zpqf_decompresser_read_segment_end(self.h)
+
+    @property
+    def last_error(self):
+        return self._L.zpqf_decompresser_last_error(self.h)
+
+    def output_bytes(self):
+        p = C.c_void_p()
+        n = self._L.zpqf_decompresser_output(self.h, C.byref(p))
+        return C.string_at(p, n) if n else b""
+
+    def get_sha1(self):
+        out = C.create_string_buffer(20)
+        self._L.zpqf_decompresser_sha1(self.h, out)
+        return out.raw
