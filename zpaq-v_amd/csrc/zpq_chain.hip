@@ -224,7 +224,9 @@ struct BitCtx {
 
 // SPEC = software-pipelined bit step (next bit's table entries fetched early, update
 // forwarded in registers); !SPEC = plain read-predict-update per bit (fewer instructions).
-template <bool DEC, bool SPEC>
+// NCH > 0: chain length (ICM + ISSEs) known at compile time and no MIX2 (levels 1-3):
+// straight-line chain and broadcast.  NCH == 0: any chain model, runtime loops.
+template <bool DEC, bool SPEC, int NCH>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -254,8 +256,10 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
     u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
 
-    const int n = cfg.n;
+    const int n = NCH ? NCH : cfg.n;
     const int last = n - 1;
+    const int nisse_end = NCH ? NCH : cfg.nisse_end;
+    const bool has_mix2 = NCH ? false : (cfg.has_mix2 != 0);
     const int ctype = (li < n) ? M.comp[li].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
     const bool is_icm = ctype == ZT_ICM, is_isse = ctype == ZT_ISSE, is_last = li == last;
@@ -413,7 +417,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE lanes: sext20
             const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
             i32 p = is_icm ? cur_pst : 0, pin = 0;
-            for (int i = 1; i < cfg.nisse_end; i++) {
+#pragma unroll
+            for (int i = 1; i < nisse_end; i++) {
                 const i32 pv = row_shr1(p);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
                 const bool me = li == i;
@@ -422,7 +427,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
             i32 pj = 0, pk = 0, wmix = 0;
             u32 mcx = 0;
-            if (cfg.has_mix2) {
+            if (has_mix2) {
                 pj = row_bcast(p, row_base + mix_j);
                 pk = row_bcast(p, row_base + mix_k);
                 if (is_last) {
@@ -468,7 +473,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 nb = nw1 >> 12;
             t32[s] = nv;
             t8[s] = (u8)nb;
-            if (cfg.has_mix2 && ctype == ZT_MIX2) {
+            if (has_mix2 && ctype == ZT_MIX2) {
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
@@ -706,22 +711,29 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     const int threads = cfg.blocks_per_wg / zpqc::BPW * 64;
     const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    const char *ev = getenv("ZPQ_CHAIN_SPEC");            // tuning knob: 0 = plain, 1 = pipelined bit step
-    const int spec = ev ? atoi(ev) : (decode ? ZPQ_CHAIN_SPEC_DEC : ZPQ_CHAIN_SPEC_ENC);
+    // encode uses the pipelined bit step, decode the plain one (measured, see above)
+    const int nch = (!cfg.has_mix2 && (cfg.n == 2 || cfg.n == 3 || cfg.n == 5)) ? cfg.n : 0;
+#define ZPQ_LAUNCH(D, S, N)                                                                              \
+    do {                                                                                                 \
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  160 * 1024);                                                           \
+        hipLaunchKernelGGL((zpqc::k_chain<D, S, N>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);    \
+    } while (0)
     if (decode) {
-        if (spec) hipLaunchKernelGGL((zpqc::k_chain<true, true>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
-        else hipLaunchKernelGGL((zpqc::k_chain<true, false>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+        switch (nch) {
+        case 2: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 2); break;
+        case 3: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 3); break;
+        case 5: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 5); break;
+        default: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 0); break;
+        }
     } else {
-        if (spec) hipLaunchKernelGGL((zpqc::k_chain<false, true>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
-        else hipLaunchKernelGGL((zpqc::k_chain<false, false>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);
+        switch (nch) {
+        case 2: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 2); break;
+        case 3: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 3); break;
+        case 5: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 5); break;
+        default: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 0); break;
+        }
     }
+#undef ZPQ_LAUNCH
     return ZPQ_OK;
 }
