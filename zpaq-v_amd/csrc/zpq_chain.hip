@@ -33,6 +33,9 @@
 
 // Measured on MI355X at two waves per SIMD (profiles/r01): the pipelined step wins for
 // encode (364 vs 373 ms), the plain one for decode (427 vs 456 ms).
+#ifndef ZPQ_CHAIN_G_DEFAULT
+#define ZPQ_CHAIN_G_DEFAULT 8
+#endif
 #ifndef ZPQ_CHAIN_SPEC_ENC
 #define ZPQ_CHAIN_SPEC_ENC 1
 #endif
@@ -69,6 +72,7 @@ struct Cfg {
     int32_t blocks_per_wg;
     int32_t lds_per_block;     // bytes
     int32_t vm_kind;
+    int32_t g;                 // lanes per block chosen on the host (8 or 16)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
     uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
     uint16_t lds_off8[G];      // ISSE c's u8 table (w1 bits 12..19); 0xFFFF = none
@@ -226,9 +230,12 @@ struct BitCtx {
 // forwarded in registers); !SPEC = plain read-predict-update per bit (fewer instructions).
 // NCH > 0: chain length (ICM + ISSEs) known at compile time and no MIX2 (levels 1-3):
 // straight-line chain and broadcast.  NCH == 0: any chain model, runtime loops.
-template <bool DEC, bool SPEC, int NCH>
+// GG = lanes per ZPAQ block (16, or 8 when the model has <= 8 components).
+template <bool DEC, bool SPEC, int NCH, int GG>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
+    constexpr int G = GG;            // shadows zpqc::G inside the kernel
+    constexpr int BPW = 64 / GG;
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -646,6 +653,12 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     if (!M->fast_kind || M->n < 1 || M->n > zpqc::G) return false;
     memset(cfg, 0, sizeof *cfg);
     cfg->n = M->n;
+    {
+        const char *ev = getenv("ZPQ_CHAIN_G");          // tuning knob
+        const int want = ev ? atoi(ev) : ZPQ_CHAIN_G_DEFAULT;
+        cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
+    }
+    const int bpwave = 64 / cfg->g;
     int off = 0, i = 0;
     if (M->comp[0].type != ZT_ICM) return false;
     for (int c = 0; c < zpqc::G; c++) cfg->lds_off8[c] = 0xFFFF;
@@ -680,9 +693,9 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     }
     const int avail = 160 * 1024 - zpqc::LDS_STATE - 1280 /*dummy tables*/ - 256;
     int bpw = avail / cfg->lds_per_block;
-    if (bpw > zpqc::MAXW * zpqc::BPW) bpw = zpqc::MAXW * zpqc::BPW;   // <= 8 waves: two per SIMD
-    bpw = bpw / zpqc::BPW * zpqc::BPW;
-    if (bpw < zpqc::BPW) return false;
+    if (bpw > 32) bpw = 32;                                           // 8 waves of 4 blocks or 4 waves of 8
+    bpw = bpw / bpwave * bpwave;
+    if (bpw < bpwave) return false;
     cfg->lds_dummy = bpw * cfg->lds_per_block;
     cfg->blocks_per_wg = bpw;
     return true;
@@ -709,31 +722,38 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
 {
     Cfg cfg;
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
-    const int threads = cfg.blocks_per_wg / zpqc::BPW * 64;
+    const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
     const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
     // encode uses the pipelined bit step, decode the plain one (measured, see above)
     const int nch = (!cfg.has_mix2 && (cfg.n == 2 || cfg.n == 3 || cfg.n == 5)) ? cfg.n : 0;
-#define ZPQ_LAUNCH(D, S, N)                                                                              \
+#define ZPQ_LAUNCH4(D, S, N, GGv)                                                                        \
     do {                                                                                                 \
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  160 * 1024);                                                           \
-        hipLaunchKernelGGL((zpqc::k_chain<D, S, N>), dim3(nwg), dim3(threads), lds, stream, *B, cfg);    \
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S, N, GGv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqc::k_chain<D, S, N, GGv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
     } while (0)
+#define ZPQ_LAUNCH(D, N)                                                                                 \
+    do {                                                                                                 \
+        if (spec) { if (cfg.g == 8) ZPQ_LAUNCH4(D, true, N, 8); else ZPQ_LAUNCH4(D, true, N, 16); }      \
+        else { if (cfg.g == 8) ZPQ_LAUNCH4(D, false, N, 8); else ZPQ_LAUNCH4(D, false, N, 16); }         \
+    } while (0)
+    const char *sev = getenv(decode ? "ZPQ_CHAIN_SPEC_DEC" : "ZPQ_CHAIN_SPEC_ENC");   // tuning knobs
+    const bool spec = sev ? atoi(sev) != 0 : (decode ? ZPQ_CHAIN_SPEC_DEC != 0 : ZPQ_CHAIN_SPEC_ENC != 0);
     if (decode) {
         switch (nch) {
-        case 2: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 2); break;
-        case 3: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 3); break;
-        case 5: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 5); break;
-        default: ZPQ_LAUNCH(true, ZPQ_CHAIN_SPEC_DEC != 0, 0); break;
+        case 2: ZPQ_LAUNCH(true, 2); break;
+        case 3: ZPQ_LAUNCH(true, 3); break;
+        case 5: ZPQ_LAUNCH(true, 5); break;
+        default: ZPQ_LAUNCH(true, 0); break;
         }
     } else {
         switch (nch) {
-        case 2: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 2); break;
-        case 3: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 3); break;
-        case 5: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 5); break;
-        default: ZPQ_LAUNCH(false, ZPQ_CHAIN_SPEC_ENC != 0, 0); break;
+        case 2: ZPQ_LAUNCH(false, 2); break;
+        case 3: ZPQ_LAUNCH(false, 3); break;
+        case 5: ZPQ_LAUNCH(false, 5); break;
+        default: ZPQ_LAUNCH(false, 0); break;
         }
     }
+#undef ZPQ_LAUNCH4
 #undef ZPQ_LAUNCH
     return ZPQ_OK;
 }
