@@ -73,6 +73,7 @@ struct Cfg {
     int32_t lds_per_block;     // bytes
     int32_t vm_kind;
     int32_t g;                 // lanes per block chosen on the host (8 or 16)
+    uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
     uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
     uint16_t lds_off8[G];      // ISSE c's u8 table (w1 bits 12..19); 0xFFFF = none
@@ -271,8 +272,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
     const bool is_icm = ctype == ZT_ICM, is_isse = ctype == ZT_ISSE, is_last = li == last;
     const DComp &C = M.comp[li < n ? li : 0];
-    u8 *ht = slot + C.ht_off;
-    const u32 ht_mask = C.ht_len - 16u;
+    // lanes without a hash table (idle, MIX2) run the same row loads against the first 64
+    // bytes of the slot: no exec-masked branch around the loads (a branch join would make
+    // the compiler wait for them at once and defeat the prefetch); only the store is masked
+    u8 *ht = hashed ? slot + C.ht_off : slot;
+    const u32 ht_mask = hashed ? ((C.ht_len - 16u) & cfg.dbg_ht_and) : 0u;
     const int sizebits = C.a + 2;
     // Packed per-block state: ICM cm[256] as u32; ISSE weights are 20-bit two's complement
     // (clamp512k, predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.
@@ -510,30 +514,89 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         };
 
         // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
+        // find_ht (predictor.v:495-532): the three candidate rows h0, h0^16, h0^32 share one
+        // 64-byte line.  select_row resolves hit / victim with selects only.
+        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, const u32 h0, const u32 chk) {
+            u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
+            const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
+            const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+            const bool va = qa <= qb && qa <= qc, vb = qb < qc;            // victim order (predictor.v:513-531)
+            const bool hit = ma || mb || mc;
+            const bool ua = ma || (!hit && va);
+            const bool ub = !ua && (mb || (!hit && vb));
+            raddr = ua ? pa : (ub ? pb : pc);
+            const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
+            X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
+        };
+        // decode: contexts depend on decoded bits, so the rows are loaded at the nibble start
         auto find_row = [&]() {
-            if (hashed) {
-                const u32 cx = hctx + 16u * X.c8;
-                const u32 chk = (cx >> sizebits) & 255u;
-                const u32 h0 = (cx * 16u) & ht_mask;
-                u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
-                const u32x4 A = *reinterpret_cast<const u32x4 *>(pa);
-                const u32x4 Bq = *reinterpret_cast<const u32x4 *>(pb);
-                const u32x4 Cq = *reinterpret_cast<const u32x4 *>(pc);
-                const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
-                const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
-                const bool va = qa <= qb && qa <= qc, vb = qb < qc;        // victim order (predictor.v:513-531)
-                const bool hit = ma || mb || mc;
-                const bool ua = ma || (!hit && va);
-                const bool ub = !ua && (mb || (!hit && vb));
-                raddr = ua ? pa : (ub ? pb : pc);
-                const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
-                X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
+            const u32 cx = hctx + 16u * X.c8;
+            const u32 chk = (cx >> sizebits) & 255u;
+            const u32 h0 = (cx * 16u) & ht_mask;
+            const u32x4 A = *reinterpret_cast<const u32x4 *>(ht + h0);
+            const u32x4 Bq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 16u));
+            const u32x4 Cq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 32u));
+            select_row(A, Bq, Cq, h0, chk);
+        };
+        // encode: every context is a function of input bytes only, so the NEXT nibble's rows
+        // are requested one nibble ahead and the HBM latency hides behind four bit steps.  If
+        // one of them is the row being updated right now, the registers win (exact).
+        u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
+        u32 n_h0 = 0, n_chk = 0;
+        auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
+            const u32 cx = hc + 16u * c8v;
+            n_chk = (cx >> sizebits) & 255u;
+            n_h0 = (cx * 16u) & ht_mask;
+            nA = *reinterpret_cast<const u32x4 *>(ht + n_h0);
+            nB = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 16u));
+            nC = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 32u));
+        };
+        // Consume the rows requested one nibble ago, THEN write the finished row back (so that
+        // the wait for the loads does not also wait for a just-issued store), then the caller
+        // requests the next nibble's rows.  The finished row is forwarded from registers if it
+        // is one of the candidates.
+        auto take_prefetched = [&](const bool have_prev) {
+            const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
+            u8 *const paddr = raddr;
+            const bool fa = have_prev && (ht + n_h0) == paddr;
+            const bool fb = have_prev && (ht + (n_h0 ^ 16u)) == paddr;
+            const bool fc = have_prev && (ht + (n_h0 ^ 32u)) == paddr;
+            const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
+            select_row(A, Bq, Cq, n_h0, n_chk);
+            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(paddr) = Rp;
+        };
+        // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
+        auto run_vm = [&](const u32 byte) -> u32 {
+            u32 hv = 0;
+            if (cfg.vm_kind == VM_HASHCHAIN) {
+                // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
+                u32 a = byte;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
+                prev = byte;
+            } else if (cfg.vm_kind == VM_LEVEL1) {
+                // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
+                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                u32 a = 0;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                const u32 h0v = a; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
+            } else {
+                if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                hv = (li < n && (u32)li < M.hlen) ? z.h[li] : 0u;
             }
+            return hv;
         };
         auto store_row = [&]() {
             if (hashed) *reinterpret_cast<uint4 *>(raddr) = make_uint4(X.r0, X.r1, X.r2, X.r3);
         };
 
+        if (!DEC) prefetch_rows(0u, 1u);
         for (u32 bi = 0; bi < total; bi++) {
             if (!DEC) {
                 if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : in_byte(bi - 1);
@@ -564,46 +627,34 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
 
             X.c8 = 1; X.slot = 1;
-            find_row();
+            u32 hnext = 0;
+            if (!DEC) {
+                hnext = run_vm(ch);                           // contexts of the NEXT byte: known now
+                take_prefetched(bi != 0);
+                prefetch_rows(hctx, 16u | (ch >> 4));         // second nibble of this byte
+            } else {
+                find_row();
+            }
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 7);
             bitstep(std::integral_constant<int, 1>{}, 6);
             bitstep(std::integral_constant<int, 2>{}, 5);
             bitstep(std::integral_constant<int, 3>{}, 4);
-            store_row();
-            find_row();
+            if (!DEC) {
+                take_prefetched(true);
+                prefetch_rows(hnext, 1u);                     // first nibble of the next byte
+            } else {
+                store_row();
+                find_row();
+            }
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 3);
             bitstep(std::integral_constant<int, 1>{}, 2);
             bitstep(std::integral_constant<int, 2>{}, 1);
             bitstep(std::integral_constant<int, 3>{}, 0);
-            store_row();
+            if (DEC) store_row();                             // encode writes it back at the next take_prefetched
             const u32 byte = X.c8 - 256;
-
-            // ---- ZPAQL.run(byte) and h[] copy (predictor.v:809-816)
-            if (cfg.vm_kind == VM_HASHCHAIN) {
-                // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
-                u32 a = byte, hv = 0;
-                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
-                hctx = hv;
-                prev = byte;
-            } else if (cfg.vm_kind == VM_LEVEL1) {
-                // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
-                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
-                u32 a = 0;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                const u32 h0v = a; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                hctx = (li == 0) ? h0v : ((li == 1) ? a : 0u);
-            } else {
-                if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                hctx = (li < n && (u32)li < M.hlen) ? z.h[li] : 0u;
-            }
+            hctx = DEC ? run_vm(byte) : hnext;
 
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
@@ -615,6 +666,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
         }
 
+        if (!DEC && total > 0) store_row();                  // the last nibble's row
         // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
         if (!DEC && is_last) {
             X.high = X.low;                                   // encode(1, 0): mid = low, high = mid
@@ -659,6 +711,10 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
     }
     const int bpwave = 64 / cfg->g;
+    {
+        const char *ev = getenv("ZPQ_DEBUG_HT_AND");     // WRONG RESULTS: cache-resident tables, timing only
+        cfg->dbg_ht_and = ev ? (uint32_t)strtoul(ev, nullptr, 0) : 0xFFFFFFFFu;
+    }
     int off = 0, i = 0;
     if (M->comp[0].type != ZT_ICM) return false;
     for (int c = 0; c < zpqc::G; c++) cfg->lds_off8[c] = 0xFFFF;
