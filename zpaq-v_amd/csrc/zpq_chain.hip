@@ -36,6 +36,9 @@
 #ifndef ZPQ_CHAIN_G_DEFAULT
 #define ZPQ_CHAIN_G_DEFAULT 8
 #endif
+#ifndef ZPQ_CHAIN_DEC_WARM
+#define ZPQ_CHAIN_DEC_WARM 0   /* measured: 352 -> 379 ms at 8192 blocks (traffic x5 on row lines) */
+#endif
 #ifndef ZPQ_CHAIN_SPEC_ENC
 #define ZPQ_CHAIN_SPEC_ENC 1
 #endif
@@ -236,6 +239,7 @@ template <bool DEC, bool SPEC, int NCH, int GG>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     constexpr int G = GG;            // shadows zpqc::G inside the kernel
+    constexpr bool WARM = ZPQ_CHAIN_DEC_WARM != 0;
     constexpr int BPW = 64 / GG;
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -383,8 +387,123 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             return v;
         };
 
+        // find_ht (predictor.v:495-532): the three candidate rows h0, h0^16, h0^32 share one
+        // 64-byte line.  select_row resolves hit / victim with selects only.
+        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, const u32 h0, const u32 chk) {
+            u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
+            const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
+            const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+            const bool va = qa <= qb && qa <= qc, vb = qb < qc;            // victim order (predictor.v:513-531)
+            const bool hit = ma || mb || mc;
+            const bool ua = ma || (!hit && va);
+            const bool ub = !ua && (mb || (!hit && vb));
+            raddr = ua ? pa : (ub ? pb : pc);
+            const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
+            X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
+        };
+        // Rows are requested AHEAD of the nibble that uses them.  Encode: every context is a
+        // function of input bytes only, so the request goes out one whole nibble early and the
+        // HBM latency hides behind four bit steps.  Decode: the request goes out inside the
+        // previous nibble's last bit step, the moment that bit is decoded, and overlaps its
+        // update work.  If a requested row is the one being updated right now, the registers
+        // win (exact forwarding in take_prefetched).
+        u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
+        u32 n_h0 = 0, n_chk = 0;
+        auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
+            const u32 cx = hc + 16u * c8v;
+            n_chk = (cx >> sizebits) & 255u;
+            n_h0 = (cx * 16u) & ht_mask;
+            nA = *reinterpret_cast<const u32x4 *>(ht + n_h0);
+            nB = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 16u));
+            nC = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 32u));
+        };
+        // Consume the rows requested one nibble ago, THEN write the finished row back (so that
+        // the wait for the loads does not also wait for a just-issued store), then the caller
+        // requests the next nibble's rows.  The finished row is forwarded from registers if it
+        // is one of the candidates.
+        auto take_prefetched = [&](const bool have_prev) {
+            const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
+            u8 *const paddr = raddr;
+            const bool fa = have_prev && (ht + n_h0) == paddr;
+            const bool fb = have_prev && (ht + (n_h0 ^ 16u)) == paddr;
+            const bool fc = have_prev && (ht + (n_h0 ^ 32u)) == paddr;
+            const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
+            select_row(A, Bq, Cq, n_h0, n_chk);
+            // keep the store BELOW the wait for the loads above (vmcnt is in-order: a store issued
+            // first would be waited for as well)
+            u8 *paddr2 = paddr;
+            asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(paddr2) : "v"(X.r0), "v"(X.r3));
+            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(paddr2) = Rp;
+        };
+        // Side-effect-free preview of run_vm for the two register-evaluated program shapes
+        // (used by the decoder to warm candidate rows before the byte is fully known)
+        auto peek_vm = [&](const u32 byte) -> u32 {
+            u32 hv = 0;
+            if (cfg.vm_kind == VM_HASHCHAIN) {
+                u32 a = byte;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
+            } else {
+                const u32 mm = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                u32 bb = b4, a = 0;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+                const u32 h0v = a; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
+            }
+            return hv;
+        };
+        // decode: cache-warming loads of the 4 candidate lines once 2 bits of a nibble are known.
+        // The values are never used for coding; they are folded into `junk` after the next real
+        // row loads have been waited for (so no extra wait) to keep the loads alive.
+        u32 junk = 0, wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;
+        auto warm4 = [&](const u32 cx0, const u32 cx1, const u32 cx2, const u32 cx3) {
+            wm0 = *reinterpret_cast<const u32 *>(ht + ((cx0 * 16u) & ht_mask));
+            wm1 = *reinterpret_cast<const u32 *>(ht + ((cx1 * 16u) & ht_mask));
+            wm2 = *reinterpret_cast<const u32 *>(ht + ((cx2 * 16u) & ht_mask));
+            wm3 = *reinterpret_cast<const u32 *>(ht + ((cx3 * 16u) & ht_mask));
+        };
+        auto warm_nibble2 = [&]() {                          // X.c8 = 1ab: second-nibble contexts 1ab00..1ab11
+            const u32 c = X.c8 << 2;
+            warm4(hctx + 16u * c, hctx + 16u * (c | 1u), hctx + 16u * (c | 2u), hctx + 16u * (c | 3u));
+        };
+        auto warm_next_byte = [&]() {                        // X.c8 = 1hhhhab: 4 candidate bytes
+            if (cfg.vm_kind != VM_GENERIC) {
+                const u32 b0 = (X.c8 << 2) - 256u;
+                warm4(peek_vm(b0) + 16u, peek_vm(b0 + 1u) + 16u, peek_vm(b0 + 2u) + 16u, peek_vm(b0 + 3u) + 16u);
+            }
+        };
+        // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
+        auto run_vm = [&](const u32 byte) -> u32 {
+            u32 hv = 0;
+            if (cfg.vm_kind == VM_HASHCHAIN) {
+                // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
+                u32 a = byte;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
+                prev = byte;
+            } else if (cfg.vm_kind == VM_LEVEL1) {
+                // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
+                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                u32 a = 0;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                const u32 h0v = a; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
+                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
+                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
+            } else {
+                if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                hv = (li < n && (u32)li < M.hlen) ? z.h[li] : 0u;
+            }
+            return hv;
+        };
         // Software-pipelined bit step.  Carried between steps: the current state byte, its
         // table entry with the previous bit's update already forwarded, and (ICM) its stretch.
+        u32 hnext_dec = 0;                                 // decode: contexts of the next byte, set in the last bit step
         u32 cur_s = 0, cur_v = 0;                          // state byte, packed entry (forwarded)
         i32 cur_b = 0, cur_pst = 0;                        // w1's top byte, ICM stretch
 
@@ -476,6 +595,13 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
             }
             if (DEC) y = bcast_down(y);
+            if (DEC && K == 3) {
+                // the nibble's last bit is known: request the next nibble's rows now, so that their
+                // latency overlaps this bit's update work (contexts: predictor.v:558-560,809-816)
+                const u32 c8n = (X.c8 << 1) | (u32)y;
+                if (bit == 4) prefetch_rows(hctx, c8n);
+                else { hnext_dec = run_vm(c8n - 256u); prefetch_rows(hnext_dec, 1u); }
+            }
             // ---- (5) update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
             const i32 err = y * 32767 - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
@@ -514,89 +640,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         };
 
         // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
-        // find_ht (predictor.v:495-532): the three candidate rows h0, h0^16, h0^32 share one
-        // 64-byte line.  select_row resolves hit / victim with selects only.
-        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, const u32 h0, const u32 chk) {
-            u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
-            const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
-            const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
-            const bool va = qa <= qb && qa <= qc, vb = qb < qc;            // victim order (predictor.v:513-531)
-            const bool hit = ma || mb || mc;
-            const bool ua = ma || (!hit && va);
-            const bool ub = !ua && (mb || (!hit && vb));
-            raddr = ua ? pa : (ub ? pb : pc);
-            const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
-            X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
-        };
-        // decode: contexts depend on decoded bits, so the rows are loaded at the nibble start
-        auto find_row = [&]() {
-            const u32 cx = hctx + 16u * X.c8;
-            const u32 chk = (cx >> sizebits) & 255u;
-            const u32 h0 = (cx * 16u) & ht_mask;
-            const u32x4 A = *reinterpret_cast<const u32x4 *>(ht + h0);
-            const u32x4 Bq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 16u));
-            const u32x4 Cq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 32u));
-            select_row(A, Bq, Cq, h0, chk);
-        };
-        // encode: every context is a function of input bytes only, so the NEXT nibble's rows
-        // are requested one nibble ahead and the HBM latency hides behind four bit steps.  If
-        // one of them is the row being updated right now, the registers win (exact).
-        u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
-        u32 n_h0 = 0, n_chk = 0;
-        auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
-            const u32 cx = hc + 16u * c8v;
-            n_chk = (cx >> sizebits) & 255u;
-            n_h0 = (cx * 16u) & ht_mask;
-            nA = *reinterpret_cast<const u32x4 *>(ht + n_h0);
-            nB = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 16u));
-            nC = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 32u));
-        };
-        // Consume the rows requested one nibble ago, THEN write the finished row back (so that
-        // the wait for the loads does not also wait for a just-issued store), then the caller
-        // requests the next nibble's rows.  The finished row is forwarded from registers if it
-        // is one of the candidates.
-        auto take_prefetched = [&](const bool have_prev) {
-            const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
-            u8 *const paddr = raddr;
-            const bool fa = have_prev && (ht + n_h0) == paddr;
-            const bool fb = have_prev && (ht + (n_h0 ^ 16u)) == paddr;
-            const bool fc = have_prev && (ht + (n_h0 ^ 32u)) == paddr;
-            const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
-            select_row(A, Bq, Cq, n_h0, n_chk);
-            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(paddr) = Rp;
-        };
-        // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
-        auto run_vm = [&](const u32 byte) -> u32 {
-            u32 hv = 0;
-            if (cfg.vm_kind == VM_HASHCHAIN) {
-                // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
-                u32 a = byte;
-                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
-                prev = byte;
-            } else if (cfg.vm_kind == VM_LEVEL1) {
-                // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
-                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
-                u32 a = 0;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                const u32 h0v = a; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
-            } else {
-                if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                hv = (li < n && (u32)li < M.hlen) ? z.h[li] : 0u;
-            }
-            return hv;
-        };
-        auto store_row = [&]() {
-            if (hashed) *reinterpret_cast<uint4 *>(raddr) = make_uint4(X.r0, X.r1, X.r2, X.r3);
-        };
 
-        if (!DEC) prefetch_rows(0u, 1u);
+        prefetch_rows(0u, 1u);                             // first nibble of the first byte: h = 0, c8 = 1
         for (u32 bi = 0; bi < total; bi++) {
             if (!DEC) {
                 if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : in_byte(bi - 1);
@@ -628,33 +673,27 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
             X.c8 = 1; X.slot = 1;
             u32 hnext = 0;
+            take_prefetched(bi != 0);                         // rows of this byte's first nibble
             if (!DEC) {
                 hnext = run_vm(ch);                           // contexts of the NEXT byte: known now
-                take_prefetched(bi != 0);
-                prefetch_rows(hctx, 16u | (ch >> 4));         // second nibble of this byte
-            } else {
-                find_row();
+                prefetch_rows(hctx, 16u | (ch >> 4));         // second nibble of this byte, a nibble ahead
             }
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 7);
             bitstep(std::integral_constant<int, 1>{}, 6);
+            if (DEC && WARM) { junk ^= wm0 ^ wm1 ^ wm2 ^ wm3; warm_nibble2(); }
             bitstep(std::integral_constant<int, 2>{}, 5);
-            bitstep(std::integral_constant<int, 3>{}, 4);
-            if (!DEC) {
-                take_prefetched(true);
-                prefetch_rows(hnext, 1u);                     // first nibble of the next byte
-            } else {
-                store_row();
-                find_row();
-            }
+            bitstep(std::integral_constant<int, 3>{}, 4);     // decode: requests the next rows inside
+            take_prefetched(true);
+            if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 3);
             bitstep(std::integral_constant<int, 1>{}, 2);
+            if (DEC && WARM) { junk ^= wm0 ^ wm1 ^ wm2 ^ wm3; warm_next_byte(); }
             bitstep(std::integral_constant<int, 2>{}, 1);
             bitstep(std::integral_constant<int, 3>{}, 0);
-            if (DEC) store_row();                             // encode writes it back at the next take_prefetched
             const u32 byte = X.c8 - 256;
-            hctx = DEC ? run_vm(byte) : hnext;
+            hctx = DEC ? hnext_dec : hnext;
 
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
@@ -666,7 +705,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
         }
 
-        if (!DEC && total > 0) store_row();                  // the last nibble's row
+        // (the last nibble's row is not written back: the slot is re-initialised for the next block)
         // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
         if (!DEC && is_last) {
             X.high = X.low;                                   // encode(1, 0): mid = low, high = mid
@@ -680,6 +719,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 X.opos++;
             }
         }
+        if (DEC && WARM && (junk ^ wm0 ^ wm1 ^ wm2 ^ wm3) == 0x9E3779B9u && nin == 0xFFFFFFFFu) status = (i32)junk;  // never true: keeps the warming loads
         const i32 st0 = row_bcast(status, row_base);           // VM status lives on lane 0
         if (is_last) {
             i32 st = st0;
