@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 else { hnext_dec = run_vm(c8n - 256u); prefetch_rows(hnext_dec, 1u); }
             }
             // ---- (5) update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
-            const i32 err = y * 32767 - sq;
+            const i32 err = (y ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
             const u32 nv = is_icm ? (y ? cm1 : cm0) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
