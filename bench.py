@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--level", type=int, default=2)
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (with --backend gloo)")
     a = ap.parse_args()
 
     import numpy as np
@@ -74,9 +77,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.single_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=a.backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -149,8 +157,9 @@ def main():
     ok = bool((d_st == 0).all()) and bool((d_dst == 0).all()) and bool((d_dlen == size).all()) \
         and bool(torch.equal(d_dec, d_in)) and bool((d_first == 0).all())
     coded_bytes = float(d_len.sum().item())
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    stats = torch.tensor([coded_bytes, 1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    rdev = dev if a.backend == "nccl" else torch.device("cpu")   # the only cross-rank traffic: two tiny reductions
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    stats = torch.tensor([coded_bytes, 1.0 if ok else 0.0], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -184,9 +193,11 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "level %d (ICM16+ISSE16+ISSE16), %d x %d B blocks per GPU (C5's per-GPU share of 65536 blocks over 8 GPUs), one segment per "
+            "config": {"workload": "level %d (ICM16+ISSE16+ISSE16), %d x %d B blocks per GPU%s, one segment per "
                                    "block, classes b mod 4 = zeros/uniform/markov-text/periodic (text blocks drawn "
-                                   "from 64 distinct generated blocks)" % (a.level, nb, size),
+                                   "from 64 distinct generated blocks)" % (
+                                       a.level, nb, size,
+                                       " (C5's per-GPU share of 65536 blocks over 8 GPUs)" if nb == 8192 else ""),
                        "blocks_per_gpu": nb, "block_bytes": size, "level": a.level,
                        "parallelism": "block b -> gpu b mod %d, no collective" % world},
             "roundtrip_bit_exact": all_ok, "ratio": round(ratio, 4),

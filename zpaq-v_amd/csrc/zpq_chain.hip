@@ -30,6 +30,7 @@
 
 #include "../../include/zpaq_hip.h"
 #include "zpq_common.h"
+#include "zpq_vm.h"
 
 // Measured on MI355X at two waves per SIMD (profiles/r01): the pipelined step wins for
 // encode (364 vs 373 ms), the plain one for decode (427 vs 456 ms).
@@ -56,7 +57,7 @@ typedef uint16_t u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G = 16;          // lanes per ZPAQ block (= one DPP row)
-constexpr int BPW = 64 / G;    // blocks per wave
+// (blocks per wave = 64 / lanes-per-block, fixed per kernel instantiation)
 constexpr int MAXW = 8;        // waves per workgroup upper bound
 
 // LDS layout of the shared read-only tables
@@ -114,111 +115,10 @@ __device__ __forceinline__ void row_set(uint4 &r, u32 slot, u32 v)
     r.w = (q == 3) ? ((r.w & m) | b) : r.w;
 }
 
-// ---- generic ZPAQL interpreter (zpaql.v:167-954) for programs that are not one
-//      of the recognised shapes; runs on lane 0 of the group, M/H/R in the slot.
-struct Vm {
-    u32 a, b, c, d;
-    i32 f, pc;
-    u8 *m; u32 mlen;
-    u32 *h; u32 hlen;
-    u32 *r;
-    const u8 *hdr;
-    i32 hdr_len, hbegin, hend;
-};
-__device__ __forceinline__ u32 m_get(const Vm &z, u32 i) { return z.mlen ? z.m[i & (z.mlen - 1)] : 0u; }
-__device__ __forceinline__ void m_set(Vm &z, u32 i, u32 v) { if (z.mlen) z.m[i & (z.mlen - 1)] = (u8)v; }
-__device__ __forceinline__ u32 h_get(const Vm &z, u32 i) { return z.hlen ? z.h[i & (z.hlen - 1)] : 0u; }
-__device__ __forceinline__ void h_set(Vm &z, u32 i, u32 v) { if (z.hlen) z.h[i & (z.hlen - 1)] = v; }
-__device__ u32 vm_src(const Vm &z, int s, u32 operand)
-{
-    switch (s) {
-    case 0: return z.a;
-    case 1: return z.b;
-    case 2: return z.c;
-    case 3: return z.d;
-    case 4: return m_get(z, z.b);
-    case 5: return m_get(z, z.c);
-    case 6: return h_get(z, z.d);
-    default: return operand;
-    }
-}
-__device__ void vm_dst(Vm &z, int t, u32 v)
-{
-    switch (t) {
-    case 0: z.a = v; break;
-    case 1: z.b = v; break;
-    case 2: z.c = v; break;
-    case 3: z.d = v; break;
-    case 4: m_set(z, z.b, v); break;
-    case 5: m_set(z, z.c, v); break;
-    default: h_set(z, z.d, v); break;
-    }
-}
-__device__ bool vm_run(Vm &z, u32 input)
-{
-    z.a = input;
-    z.pc = z.hbegin;
-    u32 steps = 0;
-    while (z.pc < z.hend && z.pc >= z.hbegin) {
-        u32 op = z.hdr[z.pc++];
-        u32 operand = 0;
-        if ((op & 7) == 7 && op != 255 && z.pc < z.hdr_len) operand = z.hdr[z.pc++];
-        else if (op == 255 && z.pc + 1 < z.hdr_len) { operand = z.hdr[z.pc] + z.hdr[z.pc + 1] * 256u; z.pc += 2; }
-        const i32 rel = (i32)((operand + 128) & 255) - 127;
-        bool go = true;
-        if (op < 56) {
-            const int t = op >> 3, k = op & 7;
-            if (k == 0) { if (t) { u32 tmp = vm_src(z, t, 0); vm_dst(z, t, z.a); z.a = tmp; } }
-            else if (k == 1) vm_dst(z, t, vm_src(z, t, 0) + 1);
-            else if (k == 2) vm_dst(z, t, vm_src(z, t, 0) - 1);
-            else if (k == 3) vm_dst(z, t, ~vm_src(z, t, 0));
-            else if (k == 4) vm_dst(z, t, 0);
-            else if (k == 7) {
-                if (t <= 3) vm_dst(z, t, z.r[operand & 255]);
-                else if (t == 4) { if (z.f != 0) z.pc += rel; }
-                else if (t == 5) { if (z.f == 0) z.pc += rel; }
-                else z.r[operand & 255] = z.a;
-            } else go = false;
-        } else if (op < 64) {
-            if (op == 56) go = false;
-            else if (op == 57) {}
-            else if (op == 59) z.a = (z.a + m_get(z, z.b) + 512u) * 773u;
-            else if (op == 60) h_set(z, z.d, (h_get(z, z.d) + z.a + 512u) * 773u);
-            else if (op == 63) z.pc += rel;
-            else go = false;
-        } else if (op < 120) vm_dst(z, (int)(op - 64) >> 3, vm_src(z, op & 7, operand));
-        else if (op < 128) go = false;
-        else if (op < 216) {
-            const u32 v = vm_src(z, op & 7, operand);
-            switch ((op - 128) >> 3) {
-            case 0: z.a += v; break;
-            case 1: z.a -= v; break;
-            case 2: z.a *= v; break;
-            case 3: if (v) z.a /= v; break;
-            case 4: if (v) z.a %= v; break;
-            case 5: z.a &= v; break;
-            case 6: z.a &= ~v; break;
-            case 7: z.a |= v; break;
-            case 8: z.a ^= v; break;
-            case 9: z.a <<= (v & 31); break;
-            default: z.a >>= (v & 31); break;
-            }
-        } else if (op < 240) {
-            const u32 v = vm_src(z, op & 7, operand);
-            const int g = (op - 216) >> 3;
-            z.f = g == 0 ? (z.a == v) : (g == 1 ? (z.a < v) : (z.a > v));
-        } else if (op == 255) {
-            if (z.pc < 2) go = false;
-            else {
-                z.pc = z.hbegin + (i32)z.hdr[z.pc - 2] + (i32)z.hdr[z.pc - 1] * 256;
-                if (z.pc >= z.hend) go = false;
-            }
-        } else go = false;
-        if (!go) break;
-        if (++steps >= ZPQ_VM_STEP_CAP) return false;
-    }
-    return true;
-}
+// Programs that are not one of the recognised shapes run through the shared interpreter
+// (zpq_vm.h) on lane 0 of the group, with M/H/R in the block's HBM slot.
+using zpqvm::Vm;
+using zpqvm::vm_run;
 
 // One coded bit for every lane of the group.  K = bit index inside the nibble
 // (0..3) selects at compile time which dword(s) of the 16-byte row can hold the
@@ -547,13 +447,18 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE lanes: sext20
             const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
             i32 p = is_icm ? cur_pst : 0, pin = 0;
-#pragma unroll
-            for (int i = 1; i < nisse_end; i++) {
+            auto chain_step = [&](const int i) {
                 const i32 pv = row_shr1(p);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
                 const bool me = li == i;
                 pin = me ? pv : pin;
                 p = me ? pn : p;
+            };
+            if (NCH) {
+#pragma unroll
+                for (int i = 1; i < (NCH ? NCH : 1); i++) chain_step(i);
+            } else {
+                for (int i = 1; i < nisse_end; i++) chain_step(i);
             }
             i32 pj = 0, pk = 0, wmix = 0;
             u32 mcx = 0;
