@@ -134,3 +134,53 @@ def test_chain_overflow_status(zpq, gpu_ctx):
     good, status, _ = gpu_ctx.encode_blocks(model, [data])
     dec, status, *_ = gpu_ctx.decode_blocks(model, good, cap=100)
     assert status[0] == -7
+
+
+def test_chain_full_size_batch_properties(zpq, gpu_ctx):
+    """BASELINE size (level 2, 8192 x 64 KiB, buffers resident in HBM): size-independent
+    properties -- encode -> decode is the identity on every block, every status is OK, the
+    decoder consumed exactly the bytes the encoder produced -- plus byte parity with the
+    CPU oracle on a random sample of blocks and a checksum of checksums over all coded
+    streams that must not depend on how blocks were grouped into launches."""
+    import torch
+    nb, size = 8192, 65536
+    arr = W.make_blocks_fast(nb, size)
+    dev = torch.device("cuda:0")
+    model = zpq.Model(level=2)
+    cap = size + size // 8 + 1024
+    d_in = torch.from_numpy(arr.reshape(-1)).to(dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    in_off = torch.arange(nb + 1, **i64) * size
+    out_off = torch.arange(nb + 1, **i64) * cap
+    d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
+    d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
+    d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
+                              out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
+    gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
+                              in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
+                              d_first.data_ptr(), d_dst.data_ptr())
+    gpu_ctx.sync()
+    assert gpu_ctx.last_slots == nb                      # all blocks resident: 32 per CU
+    assert bool((d_st == 0).all()) and bool((d_dst == 0).all())
+    assert bool((d_dlen == size).all()) and bool((d_first == 0).all())
+    assert bool(torch.equal(d_dec, d_in))
+    assert bool(torch.equal(d_cons, d_len))              # decoder pulled exactly what the encoder put
+    assert bool((d_code == -1).all())                    # Decoder.code after EOF = the 4 flush bytes FF FF FF FF
+    lens = d_len.cpu().numpy()
+    out = d_out.cpu().numpy()
+    rnd = random.Random(2024)
+    sample = sorted(rnd.sample(range(nb), 24))
+    want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=8, slack=cap)
+    for i, w in zip(sample, want):
+        assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+    # checksum of checksums: same 512 blocks coded in a separate, smaller launch
+    sub = list(range(0, nb, 16))
+    coded_sub, status, _ = gpu_ctx.encode_blocks(model, [arr[i].tobytes() for i in sub], cap=cap)
+    assert (status == 0).all()
+    h_big, h_small = hashlib.sha256(), hashlib.sha256()
+    for i, c in zip(sub, coded_sub):
+        h_big.update(hashlib.sha256(out[i * cap:i * cap + int(lens[i])].tobytes()).digest())
+        h_small.update(hashlib.sha256(c).digest())
+    assert h_big.digest() == h_small.digest()
