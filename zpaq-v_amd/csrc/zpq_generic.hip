@@ -35,6 +35,8 @@ __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b
 __device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
 
+constexpr int GEN_LDS_COMP = 32;   // 3 KiB: keeps 8 workgroups per CU
+
 struct Lds {
     i32 p[256];          // Predictor.p   (stretch domain)
     u32 h[256];          // Predictor.h   (contexts copied from the VM)
@@ -42,6 +44,7 @@ struct Lds {
     u32 cxt[256];        // Component.cxt
     DCompScal cs[ZPQ_MAX_COMP];
     u8 header[ZPQ_MAX_HDR];
+    DComp comp[GEN_LDS_COMP];   // descriptors of the first components (the rest are read from HBM)
     i32 mix_err;         // broadcast slot for the cooperative MIX update
     i32 mix_idx;
 };
@@ -113,7 +116,7 @@ __device__ i32 predict(Pred &P, const int lane)
     if (n == 0) return 16384;
     Lds &S = *P.S;
     for (i32 i = 0; i < n; i++) {
-        const DComp &c = P.M->comp[i];
+        const DComp &c = (i < GEN_LDS_COMP) ? P.S->comp[i] : P.M->comp[i];
         if (c.type == ZT_MIX) {
             // cooperative: lane l accumulates terms l, l+64, ...; shuffle-reduce
             const i32 j = c.b, m = c.limit;
@@ -224,7 +227,7 @@ __device__ void update(Pred &P, const i32 y, const int lane)
     const i32 n = P.n;
     Lds &S = *P.S;
     for (i32 i = 0; i < n; i++) {
-        const DComp &c = P.M->comp[i];
+        const DComp &c = (i < GEN_LDS_COMP) ? P.S->comp[i] : P.M->comp[i];
         if (c.type == ZT_MIX) {
             const i32 jj = c.b, m = c.limit;
             if (lane == 0) {
@@ -438,6 +441,13 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
     const int lane = threadIdx.x;
     const DModel &M = *B.model;
     for (int i = lane; i < M.hdr_len && i < ZPQ_MAX_HDR; i += 64) S.header[i] = M.header[i];
+    {
+        const int nd = (M.n < GEN_LDS_COMP ? M.n : GEN_LDS_COMP) * (int)(sizeof(DComp) / 4);
+        const u32 *src = reinterpret_cast<const u32 *>(&M.comp[0]);
+        u32 *dst = reinterpret_cast<u32 *>(&S.comp[0]);
+        for (int i = lane; i < nd; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
 
     for (int blk = blockIdx.x; blk < B.nblocks; blk += gridDim.x) {
         u8 *slot = B.slots + (u64)blockIdx.x * M.slot_bytes;
