@@ -184,3 +184,63 @@ def test_chain_full_size_batch_properties(zpq, gpu_ctx):
         h_big.update(hashlib.sha256(out[i * cap:i * cap + int(lens[i])].tobytes()).digest())
         h_small.update(hashlib.sha256(c).digest())
     assert h_big.digest() == h_small.digest()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_chain_large_blocks(zpq, gpu_ctx, level):
+    """Blocks much larger than 64 KiB: C1's 1 MiB of zeros (M array wraps 16x at level 2)
+    and 256 KiB of mixed data, against the oracle."""
+    hdr = O.level_header(level)
+    model = zpq.Model(level=level)
+    rnd = random.Random(31 + level)
+    mixed = bytes(rnd.getrandbits(8) for _ in range(65536)) + bytes(65536) + \
+        bytes(rnd.choice(b"abcdefgh\n") for _ in range(131072))
+    blocks = [bytes(1 << 20), mixed]
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks, cap=300000)
+    assert (status == 0).all()
+    assert coded == O.encode_blocks(hdr, blocks, nthreads=2, slack=300000)
+    dec, status, consumed, *_ = gpu_ctx.decode_blocks(model, coded, cap=1 << 20)
+    assert (status == 0).all() and dec == blocks
+    assert [int(c) for c in consumed] == [len(c) for c in coded]
+
+
+def test_decoder_on_garbage_terminates_with_status(zpq, gpu_ctx):
+    """Corrupt or truncated coded input must end in a per-block status (or a short
+    output), never a hang or a fault: both kernels, tiny output slabs."""
+    rnd = random.Random(77)
+    model = zpq.Model(level=2)
+    good = gpu_ctx.encode_blocks(model, [bytes(rnd.getrandbits(8) for _ in range(3000))])[0][0]
+    garbage = [bytes(rnd.getrandbits(8) for _ in range(2000)), bytes(2000), b"\xff" * 2000,
+               good[:len(good) // 2], good[:3], b""]
+    for flags in (zpq.FLAG_PP, zpq.FLAG_PP | zpq.FLAG_GENERIC):
+        dec, status, consumed, code, first = gpu_ctx.decode_blocks(model, garbage, cap=4096, flags=flags)
+        assert all(int(s) in (0, -7) for s in status)
+        assert all(len(d) <= 4096 for d in dec)
+        assert all(int(c) <= len(g) for c, g in zip(consumed, garbage))
+    # both kernels agree on what garbage decodes to (same arithmetic, same EOF handling)
+    d1 = gpu_ctx.decode_blocks(model, garbage, cap=4096, flags=zpq.FLAG_PP)
+    d2 = gpu_ctx.decode_blocks(model, garbage, cap=4096, flags=zpq.FLAG_PP | zpq.FLAG_GENERIC)
+    assert d1[0] == d2[0] and (d1[1] == d2[1]).all()
+    # and with the oracle where the oracle terminates within the slab
+    for g, d, s in zip(garbage, d1[0], d1[1]):
+        if int(s) == 0:
+            try:
+                want, _ = O.Codec(model.header).decode(g, cap=4097)
+            except OverflowError:
+                continue
+            assert want[1:] == d or (len(want) == 0 and d == b"")
+
+
+def test_empty_batch_and_bad_arguments(zpq, gpu_ctx):
+    model = zpq.Model(level=2)
+    coded, status, _ = gpu_ctx.encode_blocks(model, [])
+    assert coded == [] and len(status) == 0
+    L = zpq.lib()
+    assert L.zpq_encode_blocks(gpu_ctx.h, model.h, -1, None, None, 0, None, None, None, None) == -2
+    assert L.zpq_encode_blocks(None, model.h, 1, None, None, 0, None, None, None, None) == -2
+    off = np.array([0, 5], dtype=np.uint64)
+    bad = np.array([5, 0], dtype=np.uint64)                 # decreasing offsets
+    out = np.zeros(64, dtype=np.uint8); ol = np.zeros(1, dtype=np.uint32); st = np.zeros(1, dtype=np.int32)
+    src = np.zeros(8, dtype=np.uint8)
+    assert L.zpq_encode_blocks(gpu_ctx.h, model.h, 1, src.ctypes.data, bad.ctypes.data, 0, out.ctypes.data,
+                               off.ctypes.data, ol.ctypes.data, st.ctypes.data) == -2
