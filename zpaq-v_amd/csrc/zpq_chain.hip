@@ -660,14 +660,26 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         const char *ev = getenv("ZPQ_DEBUG_HT_AND");     // WRONG RESULTS: cache-resident tables, timing only
         cfg->dbg_ht_and = ev ? (uint32_t)strtoul(ev, nullptr, 0) : 0xFFFFFFFFu;
     }
+    // Per-block LDS layout.  Tables are indexed by the bit-history state, and lanes of
+    // different blocks / components very often hold EQUAL states, so tables whose bases share
+    // a bank (all of them, if laid out at 1 KiB multiples) collide on every access -- rocprof
+    // showed SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.67.  Component c's tables therefore
+    // start at bank c, and the per-block stride advances the bank by n, so the n * (blocks per
+    // wave) lanes of a wave land on distinct banks for equal states (exact for n*bpwave <= 32).
     int off = 0, i = 0;
+    auto place = [&](int bytes, int bank) {
+        while (((off >> 2) & 31) != (bank & 31)) off += 4;
+        const int o = off;
+        off += bytes;
+        return o;
+    };
     if (M->comp[0].type != ZT_ICM) return false;
     for (int c = 0; c < zpqc::G; c++) cfg->lds_off8[c] = 0xFFFF;
-    cfg->lds_off32[0] = (uint16_t)off; off += 1024;
+    cfg->lds_off32[0] = (uint16_t)place(1024, 0);
     for (i = 1; i < M->n && M->comp[i].type == ZT_ISSE; i++) {
         if (M->comp[i].b != i - 1) return false;               // chain: ISSE i is fed by component i-1
-        cfg->lds_off32[i] = (uint16_t)off; off += 1024;
-        cfg->lds_off8[i] = (uint16_t)off; off += 256;
+        cfg->lds_off32[i] = (uint16_t)place(1024, i);
+        cfg->lds_off8[i] = (uint16_t)place(256, i);
     }
     cfg->nisse_end = i;
     if (i < M->n) {
@@ -676,6 +688,7 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         cfg->has_mix2 = 1;
         cfg->lds_off32[i] = 0;
     }
+    while (((off >> 2) & 31) != (M->n & 31)) off += 4;         // next block starts n banks further
     cfg->lds_per_block = off;
     // recognise the shipped HCOMP programs (levels.v:73-87,126-141,...)
     cfg->vm_kind = zpqc::VM_GENERIC;
