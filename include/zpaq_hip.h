@@ -73,6 +73,10 @@ int zpq_ctx_sync(zpq_ctx *);
 void *zpq_ctx_stream(zpq_ctx *); /* the hipStream_t all launches of this ctx go to */
 /* Upper bound on state-slot memory this ctx may hold (default: 75% of free HBM). */
 int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
+/* Largest block (bytes) the caller will submit to the chain kernel for models with huge hash
+ * tables (levels 4-5): sizes their compact line store.  Default 65536.  A bigger block gets
+ * ZPQ_E_TOOBIG in status[] instead of wrong output. */
+int zpq_ctx_set_max_block_bytes(zpq_ctx *, uint64_t bytes);
 /* Resident blocks (state slots) the last batch call used; for reporting. */
 int zpq_ctx_last_slots(const zpq_ctx *);
 /* Time of the last batch's coding kernel alone, from HIP events on the ctx stream (ms). */

@@ -244,3 +244,43 @@ def test_empty_batch_and_bad_arguments(zpq, gpu_ctx):
     src = np.zeros(8, dtype=np.uint8)
     assert L.zpq_encode_blocks(gpu_ctx.h, model.h, 1, src.ctypes.data, bad.ctypes.data, 0, out.ctypes.data,
                                off.ctypes.data, ol.ctypes.data, st.ctypes.data) == -2
+
+
+def test_compact_line_store_forced_on_small_model(zpq, gpu_ctx, monkeypatch):
+    """The compact line store (dense line index -> slot, open addressing) must be invisible
+    to the coder.  Force it onto level 2 with a tiny 8192-line store so that probing and
+    collisions are exercised, and compare with the oracle and the dense run."""
+    hdr = O.level_header(2)
+    model = zpq.Model(level=2)
+    rnd = random.Random(4242)
+    blocks = mixed_blocks(rnd, 40, [0, 1, 17, 300, 1000, 1900])
+    dense, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert (status == 0).all()
+    monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "13")
+    sparse, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert (status == 0).all()
+    assert sparse == dense == O.encode_blocks(hdr, blocks, nthreads=4)
+    dec, status, *_ = gpu_ctx.decode_blocks(model, sparse, cap=4096)
+    assert (status == 0).all() and dec == blocks
+    # a block that needs more lines than the store holds is refused, not miscoded
+    monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "10")
+    big = [bytes(rnd.getrandbits(8) for _ in range(3000))]
+    _, status, _ = gpu_ctx.encode_blocks(model, big)
+    assert status[0] == -4
+
+
+def test_level5_uses_compact_store_and_matches_oracle(zpq, gpu_ctx):
+    """Level 5 (ICM22 + 7 x ISSE22 + MIX2): 2 GiB of dense tables per block becomes ~140 MiB,
+    so hundreds of blocks are resident; coded streams still equal the oracle's."""
+    model = zpq.Model(level=5)
+    hdr = O.level_header(5)
+    arr = W.make_blocks(4, 65536, start=1)
+    blocks = [arr[i].tobytes() for i in range(4)] + [b"", b"abc" * 50]
+    blocks = blocks * 40                                   # 240 blocks: far more than 2 GiB slots would allow
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks, cap=80000)
+    assert (status == 0).all()
+    assert gpu_ctx.last_slots == len(blocks)
+    want = O.encode_blocks(hdr, blocks[:6], nthreads=3, slack=80000)
+    assert coded[:6] == want and coded[6:12] == want       # same content -> same stream in any slot
+    dec, status, *_ = gpu_ctx.decode_blocks(model, coded[:12], cap=65536)
+    assert (status == 0).all() and dec == blocks[:12]

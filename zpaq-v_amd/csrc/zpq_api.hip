@@ -13,6 +13,7 @@
 // compute entry point returns ZPQ_E_NODEVICE.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -26,7 +27,9 @@
 extern "C" void zpq_launch_generic(const DBatch *B, int decode, int grid, hipStream_t stream);
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
-extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, hipStream_t stream);
+extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
+extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
+                                hipStream_t stream);
 extern "C" const char *zpq_chain_kernel_name(const DModel *M, int decode);
 
 #define HIPCK(x)                                                              \
@@ -68,7 +71,8 @@ struct zpq_ctx {
     int16_t *d_squash = nullptr, *d_stretch = nullptr, *d_dt2k = nullptr;
     uint32_t *d_dt = nullptr, *d_stretch_c = nullptr;
     uint8_t *d_ns = nullptr;
-    std::map<uint64_t, DevModel> models;
+    std::map<uint64_t, DevModel> models;   // key = model id * 64 + compact-store log2 (0 = dense layout)
+    int sparse_log2 = 18;                  // line-store capacity for blocks up to 64 KiB (+ PP byte)
     DevBuf slots;
     uint64_t budget = 0;
     int last_slots = 0;
@@ -160,6 +164,16 @@ extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes)
     c->budget = bytes;
     return ZPQ_OK;
 }
+extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
+{
+    if (!c) return ZPQ_E_ARG;
+    // a block of N bytes (+ PP byte) probes each hash table 2(N+1) times; keep the store <= 60 % full
+    const uint64_t probes = 2 * (bytes + 2);
+    int lg = 12;
+    while (lg < 26 && (uint64_t)(0.6 * (double)(1ull << lg)) < probes) lg++;
+    c->sparse_log2 = lg;
+    return ZPQ_OK;
+}
 extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return c ? c->last_slots : 0; }
 extern "C" const char *zpq_ctx_last_kernel_name(const zpq_ctx *c) { return c ? c->last_name : ""; }
 extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
@@ -171,16 +185,17 @@ extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
     return ms;
 }
 
-static int get_dev_model(zpq_ctx *c, const zpq_model *m, DevModel *out)
+static int get_dev_model(zpq_ctx *c, const zpq_model *m, const DModel &layout, int sparse_log2, DevModel *out)
 {
-    auto it = c->models.find(m->id);
+    const uint64_t key = m->id * 64 + (uint64_t)sparse_log2;
+    auto it = c->models.find(key);
     if (it != c->models.end()) { *out = it->second; return ZPQ_OK; }
     DevModel dm;
     HIPCK(hipMalloc((void **)&dm.d_model, sizeof(DModel)));
     HIPCK(hipMalloc((void **)&dm.d_img, m->img.size() * 4 + 4));
-    HIPCK(hipMemcpy(dm.d_model, &m->d, sizeof(DModel), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(dm.d_model, &layout, sizeof(DModel), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(dm.d_img, m->img.data(), m->img.size() * 4, hipMemcpyHostToDevice));
-    c->models[m->id] = dm;
+    c->models[key] = dm;
     *out = dm;
     return ZPQ_OK;
 }
@@ -205,13 +220,21 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (a.nblocks == 0) return ZPQ_OK;
     if (!a.in_off || !a.out_off || !a.out_len || !a.status) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
+    const bool want_chain = m->d.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
+                            !a.trace && !a.own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
+    // chain kernel + huge hash tables (levels 4-5): compact line store layout of the slot
+    static thread_local DModel sparse_layout;
+    int sp = 0;
+    if (want_chain) {
+        const char *ev = getenv("ZPQ_SPARSE_FORCE_LOG2");        // tests: exercise the store on small models
+        const int cap = ev ? atoi(ev) : c->sparse_log2;
+        if (cap >= 8 && cap <= 26 && zpq_sparse_layout(m->d, cap, &sparse_layout)) sp = cap;
+    }
+    const DModel &M = sp ? sparse_layout : m->d;
     DevModel dm;
-    int rc = get_dev_model(c, m, &dm);
+    int rc = get_dev_model(c, m, M, sp, &dm);
     if (rc != ZPQ_OK) return rc;
 
-    const DModel &M = m->d;
-    const bool want_chain = M.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) && !a.trace &&
-                            zpq_chain_blocks_per_wg(&M) > 0;
     DBatch B;
     memset(&B, 0, sizeof B);
     B.model = dm.d_model; B.img = dm.d_img;
@@ -224,9 +247,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
 
     const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)a.nblocks;
     if (max_by_mem == 0 && !a.own_slot) return ZPQ_E_NOMEM;
-    int nslots, grid;
+    int nslots, grid, bpw = 0;
     if (want_chain) {
-        const int bpw = zpq_chain_blocks_per_wg(&M);
+        const uint64_t can_hold = max_by_mem < (uint64_t)a.nblocks ? max_by_mem : (uint64_t)a.nblocks;
+        if (!zpq_chain_plan(&M, (int)can_hold, c->cus, &bpw)) return ZPQ_E_INTERNAL;
         int nwg = (a.nblocks + bpw - 1) / bpw;
         const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
         if (nwg > cap_wg) nwg = cap_wg;
@@ -255,7 +279,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
 
     HIPCK(hipEventRecord(c->ev0, c->stream));
     if (want_chain && !a.own_slot) {
-        rc = zpq_launch_chain(&B, &M, decode, grid, c->stream);
+        rc = zpq_launch_chain(&B, &M, decode, grid, bpw, c->stream);
         if (rc != ZPQ_OK) return rc;
         c->last_name = zpq_chain_kernel_name(&M, decode);
     } else {

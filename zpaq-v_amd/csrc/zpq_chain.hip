@@ -181,6 +181,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // the compiler wait for them at once and defeat the prefetch); only the store is masked
     u8 *ht = hashed ? slot + C.ht_off : slot;
     const u32 ht_mask = hashed ? ((C.ht_len - 16u) & cfg.dbg_ht_and) : 0u;
+    // compact line store (levels 4-5): tags[cap] + 64-byte lines[cap] instead of the dense table
+    const u32 sp_log2 = hashed ? C.sp_cap_log2 : 0u;
+    u32 *sp_tags = reinterpret_cast<u32 *>(slot + C.sp_tag_off);
+    u8 *sp_lines = slot + C.sp_line_off;
+    const u32 sp_mask = sp_log2 ? ((1u << sp_log2) - 1u) : 0u;
     const int sizebits = C.a + 2;
     // Packed per-block state: ICM cm[256] as u32; ISSE weights are 20-bit two's complement
     // (clamp512k, predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.
@@ -289,8 +294,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
         // find_ht (predictor.v:495-532): the three candidate rows h0, h0^16, h0^32 share one
         // 64-byte line.  select_row resolves hit / victim with selects only.
-        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, const u32 h0, const u32 chk) {
-            u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
+        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, u8 *pa, const u32 chk) {
+            u8 *pb = reinterpret_cast<u8 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);   // rows share a 64-B aligned line
+            u8 *pc = reinterpret_cast<u8 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
             const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
             const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
             const bool va = qa <= qb && qa <= qc, vb = qb < qc;            // victim order (predictor.v:513-531)
@@ -308,14 +314,35 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // update work.  If a requested row is the one being updated right now, the registers
         // win (exact forwarding in take_prefetched).
         u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
-        u32 n_h0 = 0, n_chk = 0;
+        u8 *n_pa = ht;
+        u32 n_chk = 0, sp_claims = 0;
         auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
             const u32 cx = hc + 16u * c8v;
             n_chk = (cx >> sizebits) & 255u;
-            n_h0 = (cx * 16u) & ht_mask;
-            nA = *reinterpret_cast<const u32x4 *>(ht + n_h0);
-            nB = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 16u));
-            nC = *reinterpret_cast<const u32x4 *>(ht + (n_h0 ^ 32u));
+            const u32 h0 = (cx * 16u) & ht_mask;
+            u8 *pa = ht + h0;
+            if (sp_log2) {
+                // dense line index -> slot of the compact store (open addressing, linear probing);
+                // a free slot is claimed, its line is still all-zero like an untouched dense line
+                const u32 key = (h0 >> 6) + 1u;
+                u32 si = ((h0 >> 6) * 0x9E3779B1u) >> (32u - sp_log2);
+                for (u32 tries = 0; tries <= sp_mask; tries++) {
+                    const u32 t = sp_tags[si];
+                    if (t == key) break;
+                    if (t == 0u) {
+                        if (sp_claims * 10u >= (sp_mask + 1u) * 9u) { status = ZPQ_E_TOOBIG; break; }  // store (nearly) full
+                        sp_tags[si] = key;
+                        sp_claims++;
+                        break;
+                    }
+                    si = (si + 1u) & sp_mask;
+                }
+                pa = sp_lines + ((u64)si << 6) + (h0 & 48u);
+            }
+            n_pa = pa;
+            nA = *reinterpret_cast<const u32x4 *>(pa);
+            nB = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);
+            nC = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
         };
         // Consume the rows requested one nibble ago, THEN write the finished row back (so that
         // the wait for the loads does not also wait for a just-issued store), then the caller
@@ -324,11 +351,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         auto take_prefetched = [&](const bool have_prev) {
             const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
             u8 *const paddr = raddr;
-            const bool fa = have_prev && (ht + n_h0) == paddr;
-            const bool fb = have_prev && (ht + (n_h0 ^ 16u)) == paddr;
-            const bool fc = have_prev && (ht + (n_h0 ^ 32u)) == paddr;
+            const uintptr_t na = reinterpret_cast<uintptr_t>(n_pa), pp = reinterpret_cast<uintptr_t>(paddr);
+            const bool fa = have_prev && na == pp;
+            const bool fb = have_prev && (na ^ 16u) == pp;
+            const bool fc = have_prev && (na ^ 32u) == pp;
             const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
-            select_row(A, Bq, Cq, n_h0, n_chk);
+            select_row(A, Bq, Cq, n_pa, n_chk);
             // keep the store BELOW the wait for the loads above (vmcnt is in-order: a store issued
             // first would be waited for as well)
             u8 *paddr2 = paddr;
@@ -625,7 +653,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
         }
         if (DEC && WARM && (junk ^ wm0 ^ wm1 ^ wm2 ^ wm3) == 0x9E3779B9u && nin == 0xFFFFFFFFu) status = (i32)junk;  // never true: keeps the warming loads
-        const i32 st0 = row_bcast(status, row_base);           // VM status lives on lane 0
+        i32 st0 = row_bcast(status, row_base);                 // VM status lives on lane 0
+        for (int c = 1; c < n; c++) { const i32 sc = row_bcast(status, row_base + c); st0 = st0 ? st0 : sc; }   // line-store overflow: any hashed lane
         if (is_last) {
             i32 st = st0;
             if (X.opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
@@ -721,6 +750,25 @@ extern "C" int zpq_chain_blocks_per_wg(const DModel *M)
     return build_cfg(M, &cfg) ? cfg.blocks_per_wg : 0;
 }
 
+// Blocks per workgroup for a batch: as few as keeps every CU busy (each wave then has a SIMD
+// to itself), never more than the LDS allows; a multiple of the blocks one wave carries.
+static int plan_blocks_per_wg(const Cfg &cfg, int nblocks, int cus)
+{
+    const int bpwave = 64 / cfg.g;
+    int want = (nblocks + cus - 1) / cus;
+    want = (want + bpwave - 1) / bpwave * bpwave;
+    if (want < bpwave) want = bpwave;
+    return want < cfg.blocks_per_wg ? want : cfg.blocks_per_wg;
+}
+
+extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg)
+{
+    Cfg cfg;
+    if (!build_cfg(M, &cfg)) return 0;
+    *blocks_per_wg = plan_blocks_per_wg(cfg, nblocks, cus);
+    return 1;
+}
+
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus)
 {
     (void)M;
@@ -732,10 +780,14 @@ extern "C" const char *zpq_chain_kernel_name(const DModel *, int decode)
     return decode ? "k_chain<decode>" : "k_chain<encode>";
 }
 
-extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, hipStream_t stream)
+extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
+                                hipStream_t stream)
 {
     Cfg cfg;
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
+    if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
+    cfg.blocks_per_wg = blocks_per_wg;
+    cfg.lds_dummy = blocks_per_wg * cfg.lds_per_block;
     const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
     const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
     // encode uses the pipelined bit step, decode the plain one (measured, see above)

@@ -22,6 +22,10 @@ uint64_t tables_fnv(int which);
 
 }  // namespace zpq
 
+// Re-lay a model's state slot with a compact line store (capacity 2^cap_log2 lines) for every
+// ICM/ISSE hash table that is at least 2x larger than the store; false if none qualifies.
+bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out);
+
 struct zpq_model {
     DModel d;
     std::vector<uint32_t> img;  // initial table contents (ICM/ISSE/SSE), uploaded per ctx

@@ -422,6 +422,42 @@ extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegi
     return ZPQ_OK;
 }
 
+// Compact line store layout.  A block of N bytes probes each hash table 2(N+1) times, so it
+// can touch at most that many 64-byte lines; the dense table (64 << sizebits bytes: 256 MiB at
+// level 5) is replaced by `cap` line slots plus a tag per slot (line index + 1).  Untouched
+// lines are zero in the dense table and lines are zeroed before use here, so the two are
+// indistinguishable to the coder ("hard parts").
+bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out)
+{
+    *out = dense;
+    DModel &D = *out;
+    const uint64_t store = (64ull + 4ull) << cap_log2;
+    bool any = false;
+    uint64_t off = D.m_off;
+    off = align_up(off + D.mlen, 256);
+    auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes, 256); return o; };
+    for (int i = 0; i < D.n; i++) {
+        DComp &c = D.comp[i];
+        if (c.cm_len) c.cm_off = take(4ull * c.cm_len);
+        if (c.ht_len) {
+            const bool hashed = c.type == ZT_ICM || c.type == ZT_ISSE;
+            if (hashed && (uint64_t)c.ht_len >= 2 * store) {
+                c.sp_cap_log2 = (uint32_t)cap_log2;
+                c.sp_tag_off = take(4ull << cap_log2);
+                c.sp_line_off = take(64ull << cap_log2);
+                c.ht_off = 0;
+                any = true;
+            } else {
+                c.ht_off = take(c.ht_len);
+            }
+        }
+        if (c.a16_len) c.a16_off = take(2ull * c.a16_len);
+    }
+    D.slot_bytes = align_up(off, 256);
+    D.zero_bytes = D.slot_bytes;
+    return any;
+}
+
 extern "C" int zpq_model_create_level(int level, zpq_model **out)
 {
     uint8_t h[128];
