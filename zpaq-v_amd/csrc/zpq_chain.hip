@@ -77,6 +77,7 @@ struct Cfg {
     int32_t lds_per_block;     // bytes
     int32_t vm_kind;
     int32_t g;                 // lanes per block chosen on the host (8 or 16)
+    int32_t nch_spec;          // compile-time specialisation picked on the host: chain length (0 = runtime path)
     uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
     uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
@@ -132,10 +133,11 @@ struct BitCtx {
 
 // SPEC = software-pipelined bit step (next bit's table entries fetched early, update
 // forwarded in registers); !SPEC = plain read-predict-update per bit (fewer instructions).
-// NCH > 0: chain length (ICM + ISSEs) known at compile time and no MIX2 (levels 1-3):
-// straight-line chain and broadcast.  NCH == 0: any chain model, runtime loops.
+// NCH > 0: chain length (ICM + ISSEs) known at compile time, MIXT = a MIX2 follows it (levels
+// 1-3: 2/3/5 without, level 4: 6 with, level 5: 8 with): straight-line chain and broadcast.
+// NCH == 0: any chain model, runtime loops.
 // GG = lanes per ZPAQ block (16, or 8 when the model has <= 8 components).
-template <bool DEC, bool SPEC, int NCH, int GG>
+template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     constexpr int G = GG;            // shadows zpqc::G inside the kernel
@@ -168,10 +170,10 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
     u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
 
-    const int n = NCH ? NCH : cfg.n;
+    const int n = NCH ? NCH + (MIXT ? 1 : 0) : cfg.n;
     const int last = n - 1;
     const int nisse_end = NCH ? NCH : cfg.nisse_end;
-    const bool has_mix2 = NCH ? false : (cfg.has_mix2 != 0);
+    const bool has_mix2 = NCH ? MIXT : (cfg.has_mix2 != 0);
     const int ctype = (li < n) ? M.comp[li].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
     const bool is_icm = ctype == ZT_ICM, is_isse = ctype == ZT_ISSE, is_last = li == last;
@@ -684,7 +686,6 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         const int want = ev ? atoi(ev) : ZPQ_CHAIN_G_DEFAULT;
         cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
     }
-    const int bpwave = 64 / cfg->g;
     {
         const char *ev = getenv("ZPQ_DEBUG_HT_AND");     // WRONG RESULTS: cache-resident tables, timing only
         cfg->dbg_ht_and = ev ? (uint32_t)strtoul(ev, nullptr, 0) : 0xFFFFFFFFu;
@@ -717,6 +718,12 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         cfg->has_mix2 = 1;
         cfg->lds_off32[i] = 0;
     }
+    {
+        const int nch = cfg->nisse_end;
+        const bool spec = cfg->has_mix2 ? (nch == 6 || nch == 8) : (nch == 2 || nch == 3 || nch == 5);
+        cfg->nch_spec = spec ? nch : 0;
+        if (spec) cfg->g = (M->n <= 8) ? 8 : 16;              // specialised kernels exist for one G each
+    }
     while (((off >> 2) & 31) != (M->n & 31)) off += 4;         // next block starts n banks further
     cfg->lds_per_block = off;
     // recognise the shipped HCOMP programs (levels.v:73-87,126-141,...)
@@ -734,11 +741,12 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         if (plen == (int)sizeof l1 && memcmp(p, l1, sizeof l1) == 0 && M->mlen == 4 && M->hlen == 2 && M->n == 2)
             cfg->vm_kind = zpqc::VM_LEVEL1;
     }
+    const int bpwave2 = 64 / cfg->g;   // blocks one wave carries
     const int avail = 160 * 1024 - zpqc::LDS_STATE - 1280 /*dummy tables*/ - 256;
     int bpw = avail / cfg->lds_per_block;
     if (bpw > 32) bpw = 32;                                           // 8 waves of 4 blocks or 4 waves of 8
-    bpw = bpw / bpwave * bpwave;
-    if (bpw < bpwave) return false;
+    bpw = bpw / bpwave2 * bpwave2;
+    if (bpw < bpwave2) return false;
     cfg->lds_dummy = bpw * cfg->lds_per_block;
     cfg->blocks_per_wg = bpw;
     return true;
@@ -791,35 +799,27 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
     const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
     // encode uses the pipelined bit step, decode the plain one (measured, see above)
-    const int nch = (!cfg.has_mix2 && (cfg.n == 2 || cfg.n == 3 || cfg.n == 5)) ? cfg.n : 0;
-#define ZPQ_LAUNCH4(D, S, N, GGv)                                                                        \
+#define ZPQ_LAUNCH(D, N, MX, GGv)                                                                        \
     do {                                                                                                 \
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S, N, GGv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((zpqc::k_chain<D, S, N, GGv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
+        constexpr bool S_ = (D) ? (ZPQ_CHAIN_SPEC_DEC != 0) : (ZPQ_CHAIN_SPEC_ENC != 0);                 \
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S_, N, MX, GGv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqc::k_chain<D, S_, N, MX, GGv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
     } while (0)
-#define ZPQ_LAUNCH(D, N)                                                                                 \
+#define ZPQ_DISPATCH(D)                                                                                  \
     do {                                                                                                 \
-        if (spec) { if (cfg.g == 8) ZPQ_LAUNCH4(D, true, N, 8); else ZPQ_LAUNCH4(D, true, N, 16); }      \
-        else { if (cfg.g == 8) ZPQ_LAUNCH4(D, false, N, 8); else ZPQ_LAUNCH4(D, false, N, 16); }         \
+        switch (cfg.nch_spec) {                                                                          \
+        case 2: ZPQ_LAUNCH(D, 2, false, 8); break;      /* level 1 */                                    \
+        case 3: ZPQ_LAUNCH(D, 3, false, 8); break;      /* level 2 */                                    \
+        case 5: ZPQ_LAUNCH(D, 5, false, 8); break;      /* level 3 */                                    \
+        case 6: ZPQ_LAUNCH(D, 6, true, 8); break;       /* level 4 */                                    \
+        case 8: ZPQ_LAUNCH(D, 8, true, 16); break;      /* level 5 */                                    \
+        default:                                                                                         \
+            if (cfg.g == 8) ZPQ_LAUNCH(D, 0, false, 8); else ZPQ_LAUNCH(D, 0, false, 16);                \
+            break;                                                                                       \
+        }                                                                                                \
     } while (0)
-    const char *sev = getenv(decode ? "ZPQ_CHAIN_SPEC_DEC" : "ZPQ_CHAIN_SPEC_ENC");   // tuning knobs
-    const bool spec = sev ? atoi(sev) != 0 : (decode ? ZPQ_CHAIN_SPEC_DEC != 0 : ZPQ_CHAIN_SPEC_ENC != 0);
-    if (decode) {
-        switch (nch) {
-        case 2: ZPQ_LAUNCH(true, 2); break;
-        case 3: ZPQ_LAUNCH(true, 3); break;
-        case 5: ZPQ_LAUNCH(true, 5); break;
-        default: ZPQ_LAUNCH(true, 0); break;
-        }
-    } else {
-        switch (nch) {
-        case 2: ZPQ_LAUNCH(false, 2); break;
-        case 3: ZPQ_LAUNCH(false, 3); break;
-        case 5: ZPQ_LAUNCH(false, 5); break;
-        default: ZPQ_LAUNCH(false, 0); break;
-        }
-    }
-#undef ZPQ_LAUNCH4
+    if (decode) ZPQ_DISPATCH(true); else ZPQ_DISPATCH(false);
+#undef ZPQ_DISPATCH
 #undef ZPQ_LAUNCH
     return ZPQ_OK;
 }
