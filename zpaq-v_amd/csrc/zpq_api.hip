@@ -24,7 +24,8 @@
 #include "zpq_common.h"
 #include "zpq_host.h"
 
-extern "C" void zpq_launch_generic(const DBatch *B, int decode, int grid, hipStream_t stream);
+extern "C" void zpq_launch_generic(const DBatch *B, const DModel *hostM, int decode, int grid, hipStream_t stream);
+extern "C" int zpq_generic_blocks_per_cu(const DModel *M);
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
@@ -261,7 +262,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         grid = nwg;
     } else {
         nslots = a.nblocks;
-        const int cap_res = c->cus * 8;
+        const int cap_res = c->cus * zpq_generic_blocks_per_cu(&M);
         if (nslots > cap_res) nslots = cap_res;
         if (!a.own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
         grid = nslots;
@@ -283,7 +284,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         if (rc != ZPQ_OK) return rc;
         c->last_name = zpq_chain_kernel_name(&M, decode);
     } else {
-        zpq_launch_generic(&B, decode, grid, c->stream);
+        zpq_launch_generic(&B, &M, decode, grid, c->stream);
         c->last_name = decode ? "k_generic<decode>" : "k_generic<encode>";
     }
     HIPCK(hipGetLastError());

@@ -35,19 +35,27 @@ __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b
 __device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
 
-constexpr int GEN_LDS_COMP = 32;   // 3 KiB: keeps 8 workgroups per CU
+constexpr int GEN_LDS_COMP = 32;   // component descriptors cached in LDS (the rest are read from HBM)
 
+// Per-block scratch in LDS, carved from dynamic shared memory and sized by the model (about
+// 1.5 KiB for a 9-component model), so that residency is set by registers, not by LDS.
 struct Lds {
-    i32 p[256];          // Predictor.p   (stretch domain)
-    u32 h[256];          // Predictor.h   (contexts copied from the VM)
-    i32 row[256];        // Component.c for ICM/ISSE: current hash row byte index
-    u32 cxt[256];        // Component.cxt
-    DCompScal cs[ZPQ_MAX_COMP];
-    u8 header[ZPQ_MAX_HDR];
-    DComp comp[GEN_LDS_COMP];   // descriptors of the first components (the rest are read from HBM)
-    i32 mix_err;         // broadcast slot for the cooperative MIX update
-    i32 mix_idx;
+    i32 *p;              // Predictor.p   (stretch domain)            [n]
+    u32 *h;              // Predictor.h   (contexts copied from the VM) [n]
+    i32 *row;            // Component.c for ICM/ISSE: current hash row byte index [n]
+    u32 *cxt;            // Component.cxt                              [n]
+    DCompScal *cs;       // MATCH scalars                              [n]
+    u8 *header;          // COMP+HCOMP bytes                           [hdr_len]
+    DComp *comp;         // descriptors of the first components        [min(n, GEN_LDS_COMP)]
+    i32 *mix;            // [0] err, [1] idx: broadcast slots for the cooperative MIX
 };
+
+__host__ __device__ inline size_t gen_lds_bytes(int n, int hdr_len)
+{
+    const int nc = n < GEN_LDS_COMP ? n : GEN_LDS_COMP;
+    return (size_t)nc * sizeof(DComp) + (size_t)n * sizeof(DCompScal) + (size_t)n * 16 + 16 +
+           (((size_t)hdr_len + 15) & ~(size_t)15) + 16;
+}
 
 struct Tab {
     const int16_t *squash, *stretch, *dt2k;
@@ -124,10 +132,10 @@ __device__ i32 predict(Pred &P, const int lane)
             if (lane == 0) {
                 const u32 cx = (u32)(wadd((i32)S.h[i], (i32)P.c8 & c.mask) & (c.c - 1));
                 S.cxt[i] = cx;
-                S.mix_idx = (i32)cx * m;
+                S.mix[1] = (i32)cx * m;
             }
             __syncthreads();
-            idx = S.mix_idx;
+            idx = S.mix[1];
             const u32 *cm = reinterpret_cast<const u32 *>(P.slot + c.cm_off);
             i32 part = 0;
             for (i32 l = lane; l < m && (j + l) < n; l += 64)
@@ -231,11 +239,11 @@ __device__ void update(Pred &P, const i32 y, const int lane)
         if (c.type == ZT_MIX) {
             const i32 jj = c.b, m = c.limit;
             if (lane == 0) {
-                S.mix_err = wmul(y * 32767 - squash(P.T, S.p[i]), c.rate) >> 4;
-                S.mix_idx = (i32)S.cxt[i] * m;
+                S.mix[0] = wmul(y * 32767 - squash(P.T, S.p[i]), c.rate) >> 4;
+                S.mix[1] = (i32)S.cxt[i] * m;
             }
             __syncthreads();
-            const i32 err = S.mix_err, idx = S.mix_idx;
+            const i32 err = S.mix[0], idx = S.mix[1];
             u32 *cm = reinterpret_cast<u32 *>(P.slot + c.cm_off);
             for (i32 l = lane; l < m && (jj + l) < n; l += 64)
                 cm[idx + l] = (u32)clamp512k(
@@ -437,7 +445,21 @@ __device__ void init_slot(const DBatch &B, u8 *slot, const int lane)
 template <bool DEC>
 __global__ void __launch_bounds__(64) k_generic(const DBatch B)
 {
-    __shared__ Lds S;
+    extern __shared__ __align__(16) u8 gen_lds[];
+    Lds S;
+    {
+        const DModel &M0 = *B.model;
+        const int nc = M0.n < GEN_LDS_COMP ? M0.n : GEN_LDS_COMP;
+        u8 *q = gen_lds;
+        S.comp = reinterpret_cast<DComp *>(q); q += (size_t)nc * sizeof(DComp);
+        S.cs = reinterpret_cast<DCompScal *>(q); q += (size_t)M0.n * sizeof(DCompScal);
+        S.p = reinterpret_cast<i32 *>(q); q += (size_t)M0.n * 4;
+        S.h = reinterpret_cast<u32 *>(q); q += (size_t)M0.n * 4;
+        S.row = reinterpret_cast<i32 *>(q); q += (size_t)M0.n * 4;
+        S.cxt = reinterpret_cast<u32 *>(q); q += (size_t)M0.n * 4;
+        S.mix = reinterpret_cast<i32 *>(q); q += 16;
+        S.header = q;
+    }
     const int lane = threadIdx.x;
     const DModel &M = *B.model;
     for (int i = lane; i < M.hdr_len && i < ZPQ_MAX_HDR; i += 64) S.header[i] = M.header[i];
@@ -569,8 +591,21 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
 
 }  // namespace zpqg
 
-extern "C" void zpq_launch_generic(const DBatch *B, int decode, int grid, hipStream_t stream)
+extern "C" size_t zpq_generic_lds_bytes(const DModel *M) { return zpqg::gen_lds_bytes(M->n, M->hdr_len); }
+
+// resident one-wave workgroups per CU for this model (registers and LDS decide)
+extern "C" int zpq_generic_blocks_per_cu(const DModel *M)
 {
-    if (decode) hipLaunchKernelGGL(zpqg::k_generic<true>, dim3(grid), dim3(64), 0, stream, *B);
-    else hipLaunchKernelGGL(zpqg::k_generic<false>, dim3(grid), dim3(64), 0, stream, *B);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)zpqg::k_generic<false>, 64,
+                                                     zpq_generic_lds_bytes(M)) != hipSuccess || nb < 1)
+        nb = 8;
+    return nb > 32 ? 32 : nb;
+}
+
+extern "C" void zpq_launch_generic(const DBatch *B, const DModel *hostM, int decode, int grid, hipStream_t stream)
+{
+    const size_t lds = zpq_generic_lds_bytes(hostM);
+    if (decode) hipLaunchKernelGGL(zpqg::k_generic<true>, dim3(grid), dim3(64), lds, stream, *B);
+    else hipLaunchKernelGGL(zpqg::k_generic<false>, dim3(grid), dim3(64), lds, stream, *B);
 }
