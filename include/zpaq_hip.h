@@ -47,6 +47,7 @@ extern "C" {
                                  decode: drop the first decoded byte (the PP byte) from the output
                                  and report it in first_byte[] (decompressor.v:469-475). */
 #define ZPQ_FLAG_GENERIC 2u   /* force the generic all-component interpreter kernel */
+#define ZPQ_FLAG_LANES 8u     /* force the lane-per-component kernel (any model with <= 64 components) */
 #define ZPQ_FLAG_NOEOF 4u     /* encode: stop after the last data byte, no compress(-1)/flush().  Only the
                                  reference's component-less end_segment path needs it (compressor.v:364). */
 

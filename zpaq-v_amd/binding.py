@@ -12,6 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 FLAG_PP = 1
 FLAG_GENERIC = 2
+FLAG_LANES = 8
 _LIB = None
 
 

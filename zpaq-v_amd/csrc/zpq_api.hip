@@ -26,6 +26,9 @@
 
 extern "C" void zpq_launch_generic(const DBatch *B, const DModel *hostM, int decode, int grid, hipStream_t stream);
 extern "C" int zpq_generic_blocks_per_cu(const DModel *M);
+extern "C" int zpq_lanes_supported(const DModel *M);
+extern "C" int zpq_lanes_blocks_per_cu(const DModel *M);
+extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode, int nslots, hipStream_t stream);
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
@@ -221,7 +224,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (a.nblocks == 0) return ZPQ_OK;
     if (!a.in_off || !a.out_off || !a.out_len || !a.status) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
-    const bool want_chain = m->d.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
+    const bool want_chain = m->d.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
                             !a.trace && !a.own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
     // chain kernel + huge hash tables (levels 4-5): compact line store layout of the slot
     static thread_local DModel sparse_layout;
@@ -232,6 +235,9 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         if (cap >= 8 && cap <= 26 && zpq_sparse_layout(m->d, cap, &sparse_layout)) sp = cap;
     }
     const DModel &M = sp ? sparse_layout : m->d;
+    // everything else with up to 64 components: one block per wave, lane i = component i
+    const bool want_lanes = !want_chain && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY | ZB_KEEP_STATE)) &&
+                            !a.trace && !a.own_slot && zpq_lanes_supported(&m->d);
     DevModel dm;
     int rc = get_dev_model(c, m, M, sp, &dm);
     if (rc != ZPQ_OK) return rc;
@@ -262,7 +268,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         grid = nwg;
     } else {
         nslots = a.nblocks;
-        const int cap_res = c->cus * zpq_generic_blocks_per_cu(&M);
+        const int cap_res = c->cus * (want_lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
         if (nslots > cap_res) nslots = cap_res;
         if (!a.own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
         grid = nslots;
@@ -283,6 +289,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         rc = zpq_launch_chain(&B, &M, decode, grid, bpw, c->stream);
         if (rc != ZPQ_OK) return rc;
         c->last_name = zpq_chain_kernel_name(&M, decode);
+    } else if (want_lanes) {
+        rc = zpq_launch_lanes(&B, &M, decode, nslots, c->stream);
+        if (rc != ZPQ_OK) return rc;
+        c->last_name = decode ? "k_lanes<decode>" : "k_lanes<encode>";
     } else {
         zpq_launch_generic(&B, &M, decode, grid, c->stream);
         c->last_name = decode ? "k_generic<decode>" : "k_generic<encode>";

@@ -1,0 +1,476 @@
+// zpq_lanes.hip -- the all-component-types kernel in wave-parallel form: one ZPAQ block per
+// wave, LANE i OWNS COMPONENT i (n <= 64).  Any model the reference accepts: CONST, CM, ICM,
+// MATCH, AVG, MIX2, MIX, ISSE, SSE in any order, any ZPAQL program.
+//
+// Why: a component's table address depends only on contexts (h[i], c8, hmap4), never on
+// another component's prediction, so the ~35 dependent HBM loads per bit that the lane-0
+// interpreter (zpq_generic.hip) walks one after another are issued here by all lanes at once:
+//   A. every lane fetches its own component's state (CM slot, ICM/ISSE row + table entry,
+//      MATCH history byte, MIX2 weight) -- one memory latency for the whole model;
+//   B. predictions resolve in dependency order through an LDS array p[]: components without
+//      p-inputs (CONST/CM/ICM/MATCH) first, all together; then AVG/MIX2/ISSE/SSE one by one on
+//      their own lane, and MIX as a dot product over ALL lanes (lane l takes weight l) reduced
+//      with wavefront shuffles;
+//   C. the coder runs on the lane of the last component; the decoded bit comes back through
+//      v_readlane (one block per wave => it is wave-uniform);
+//   D. every lane trains its own component (MIX again across lanes);
+//   E. c8/hmap4 advance; bit-history rows are written back per nibble, ZPAQL runs per byte on
+//      lane 0 (shared interpreter, zpq_vm.h).
+// Tables squash / compact stretch / ns / dt / dt2k live in LDS, shared by the 4 waves (blocks)
+// of a workgroup; component state stays in the block's HBM slot (same layout as
+// zpq_generic.hip, which remains the fallback for n > 64 and multi-segment blocks).
+//
+// Reference behaviour reproduced (file:line under the reference's zpaq/):
+//   predict predictor.v:536-668  update predictor.v:672-824  find_ht predictor.v:495-532
+//   Encoder encoder.v:48-139     Decoder decoder.v:29-145     ZPAQL zpaql.v:167-954
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/zpaq_hip.h"
+#include "zpq_common.h"
+#include "zpq_vm.h"
+
+namespace zpql {
+
+typedef int32_t i32;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using zpqvm::Vm;
+using zpqvm::vm_run;
+
+constexpr int WAVES = 4;                         // blocks per workgroup
+constexpr int L_STRETCH = 0;                     // u32[2048+128]
+constexpr int L_SQUASH = (2048 + 128) * 4;       // u16[4096]
+constexpr int L_NS = L_SQUASH + 4096 * 2;        // u8[1024]
+constexpr int L_DT = L_NS + 1024;                // u32[1024]
+constexpr int L_DT2K = L_DT + 4096;              // i16[256]
+constexpr int L_HDR = L_DT2K + 512;              // u8[ZPQ_MAX_HDR]
+constexpr int L_WAVE = L_HDR + ZPQ_MAX_HDR;      // per-wave scratch follows
+constexpr int W_P = 0;                           // i32 p[64]
+constexpr int W_ROW = 256;                       // u8 row[64][16]
+constexpr int W_BYTES = 256 + 1024;
+constexpr int LDS_TOTAL = L_WAVE + WAVES * W_BYTES;
+
+// components whose prediction needs other components' predictions, in index order
+struct LCfg {
+    int32_t n, ndep;
+    uint8_t dep[64];
+    uint8_t dep_type[64];
+};
+
+__device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+__device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
+__device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
+__device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
+__device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
+
+template <bool DEC>
+__global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg cfg)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const DModel &M = *B.model;
+    const int tid = threadIdx.x;
+    {
+        u32 *st = reinterpret_cast<u32 *>(lds + L_STRETCH);
+        for (int i = tid; i < 2048 + 128; i += 64 * WAVES) st[i] = B.stretch_c[i];
+        u16 *sq = reinterpret_cast<u16 *>(lds + L_SQUASH);
+        for (int i = tid; i < 4096; i += 64 * WAVES) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 1024; i += 64 * WAVES) lds[L_NS + i] = B.ns[i];
+        u32 *dt = reinterpret_cast<u32 *>(lds + L_DT);
+        for (int i = tid; i < 1024; i += 64 * WAVES) dt[i] = B.dt[i];
+        int16_t *d2 = reinterpret_cast<int16_t *>(lds + L_DT2K);
+        for (int i = tid; i < 256; i += 64 * WAVES) d2[i] = B.dt2k[i];
+        for (int i = tid; i < M.hdr_len && i < ZPQ_MAX_HDR; i += 64 * WAVES) lds[L_HDR + i] = M.header[i];
+    }
+    __syncthreads();
+    const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + L_STRETCH);
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + L_SQUASH);
+    const u8 *s_ns = lds + L_NS;
+    const u32 *s_dt = reinterpret_cast<const u32 *>(lds + L_DT);
+    const int16_t *s_dt2k = reinterpret_cast<const int16_t *>(lds + L_DT2K);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    i32 *P = reinterpret_cast<i32 *>(lds + L_WAVE + wave * W_BYTES + W_P);
+    u8 *myrow = lds + L_WAVE + wave * W_BYTES + W_ROW + lane * 16;
+
+    const int n = cfg.n;
+    const int last = n - 1;
+    const bool act = lane < n;
+    const int slot_id = blockIdx.x * WAVES + wave;
+    const int nslots = B.nslots;
+    u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
+
+    // this lane's component (predictor.v:239-265 as Predictor.init leaves it)
+    const DComp &C = M.comp[act ? lane : 0];
+    const int type = act ? C.type : 0;
+    const i32 ca = C.a, cb = C.b, cc = C.c, climit = C.limit, cj = C.j, ck = C.k, crate = C.rate, cmask = C.mask;
+    const u32 cm_len = C.cm_len, ht_len = C.ht_len;
+    u32 *cm = reinterpret_cast<u32 *>(slot + C.cm_off);
+    u8 *ht = slot + C.ht_off;
+    u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
+    const bool hashed = type == ZT_ICM || type == ZT_ISSE;
+
+    auto squash = [&](i32 d) -> i32 { return s_squash[min(max(wadd(d, 2047), 0), 4093)]; };      // predictor.v:193-202
+    auto stretch = [&](i32 pr) -> i32 {                                                           // predictor.v:205-214
+        const u32 q = (u32)min(max(pr, 1), 32767);
+        const u32 wv = s_stretch[q >> 4];
+        const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+        const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+        const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+        return (q < 64u || q >= 32704u) ? endv : midv;
+    };
+
+    for (int blk = slot_id; slot_id < nslots && blk < B.nblocks; blk += nslots) {
+        // ---- Predictor.init + ZPAQL.clear (predictor.v:325-470, zpaql.v:54-95): the wave zeroes
+        //      its slot with 16-B stores, then fills the non-zero tables
+        {
+            uint4 *z4 = reinterpret_cast<uint4 *>(slot);
+            const u64 n16 = M.zero_bytes / 16;
+            const uint4 zero = make_uint4(0, 0, 0, 0);
+            for (u64 i = lane; i < n16; i += 64) z4[i] = zero;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (i32 ci = 0; ci < n; ci++) {
+                const DComp &c = M.comp[ci];
+                if (c.cm_len && c.cm_fill != ZF_ZERO) {
+                    u32 *t = reinterpret_cast<u32 *>(slot + c.cm_off);
+                    if (c.cm_fill == ZF_CONST) { for (u32 i = lane; i < c.cm_len; i += 64) t[i] = c.cm_fill_val; }
+                    else { const u32 *img = B.img + c.cm_fill_val; for (u32 i = lane; i < c.cm_len; i += 64) t[i] = img[i % c.cm_pat_len]; }
+                }
+                if (c.a16_len && c.a16_fill) {
+                    u16 *t = reinterpret_cast<u16 *>(slot + c.a16_off);
+                    for (u32 i = lane; i < c.a16_len; i += 64) t[i] = (u16)c.a16_fill;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        P[lane] = 0;                                          // Predictor.p starts at 0 (predictor.v:326)
+        for (int k = 0; k < 4; k++) reinterpret_cast<u32 *>(myrow)[k] = 0;
+
+        const u8 *src = B.in + B.in_off[blk];
+        const u32 nin = (u32)(B.in_off[blk + 1] - B.in_off[blk]);
+        u8 *dst = B.out + B.out_off[blk];
+        const u32 cap = (u32)(B.out_off[blk + 1] - B.out_off[blk]);
+        i32 status = ZPQ_OK;
+
+        Vm z;
+        z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0;
+        z.m = slot + M.m_off; z.mlen = M.mlen;
+        z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
+        z.r = reinterpret_cast<u32 *>(slot + M.r_off);
+        z.hdr = lds + L_HDR; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
+
+        // per-lane component state
+        u32 hctx = 0, cxt = 0, v0 = 0, v1 = 0, st = 0;
+        i32 pown = 0;
+        u8 *raddr = ht;
+        bool row_live = false;
+        // MATCH: a = len, b = offset, c = predicted bit, cxt = bit position, limit = buffer position.
+        // Quirk: init leaves sizebits/bufbits in a/b (predictor.v:372-373,566-572).
+        i32 ma = (type == ZT_MATCH) ? ca : 0, mb = (type == ZT_MATCH) ? cb : 0, mc = 0, mlimit = 0;
+        u32 mcxt = 0;
+        // SSE keeps both table entries it interpolated between
+        u32 sse_idx = 0;
+
+        u32 c8 = 1, hmap4 = 1;
+        u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, ipos = 0, first = 0xFFFFFFFFu;
+        bool got_first = false;
+        if (DEC && lane == last)
+            for (int k = 0; k < 4; k++) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+        const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
+
+        for (u32 bi = 0; bi < total; bi++) {
+            u32 ch = 0;
+            if (!DEC) {
+                if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : src[bi - 1];
+                else ch = src[bi];
+            }
+            // ---- EOF flag (encoder.v:108 / decoder.v:128)
+            i32 eof = 0;
+            if (lane == last) {
+                if (!DEC) low += 1;
+                else { if (code <= low) { eof = 1; high = low; } else low += 1; }
+                while ((high ^ low) < 0x1000000u) {
+                    if (!DEC) { if (opos < cap) dst[opos] = (u8)(high >> 24); opos++; }
+                    low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                    if (DEC) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+                }
+            }
+            if (DEC) { eof = __builtin_amdgcn_readlane(eof, last); if (eof) break; }
+
+            for (int bit = 7; bit >= 0; bit--) {
+                const bool nib = (c8 == 1) || ((c8 & 0xf0u) == 16u);
+                const u32 slotn = hmap4 & 15u;
+                // ================= A. every lane fetches its component's state =================
+                if (type == ZT_CM) {
+                    cxt = hctx ^ hmap4;
+                    v0 = cm[(i32)cxt & (i32)(cm_len - 1)];
+                } else if (hashed) {
+                    if (nib) {                                   // find_ht (predictor.v:495-532)
+                        const u32 cx = hctx + 16u * c8;
+                        const u32 chk = (cx >> (ca + 2)) & 255u;
+                        const u32 h0 = (cx * 16u) & (ht_len - 16u);
+                        u8 *pa = ht + h0, *pb = ht + (h0 ^ 16u), *pc = ht + (h0 ^ 32u);
+                        const u32x4 A = *reinterpret_cast<const u32x4 *>(pa);
+                        const u32x4 Bq = *reinterpret_cast<const u32x4 *>(pb);
+                        const u32x4 Cq = *reinterpret_cast<const u32x4 *>(pc);
+                        const bool ma_ = (A.x & 255u) == chk, mb_ = (Bq.x & 255u) == chk, mc_ = (Cq.x & 255u) == chk;
+                        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+                        const bool va = qa <= qb && qa <= qc, vb = qb < qc;
+                        const bool hit = ma_ || mb_ || mc_;
+                        const bool ua = ma_ || (!hit && va);
+                        const bool ub = !ua && (mb_ || (!hit && vb));
+                        raddr = ua ? pa : (ub ? pb : pc);
+                        const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
+                        u32 *rw = reinterpret_cast<u32 *>(myrow);
+                        rw[0] = hit ? Rr.x : chk; rw[1] = hit ? Rr.y : 0u; rw[2] = hit ? Rr.z : 0u; rw[3] = hit ? Rr.w : 0u;
+                        row_live = true;
+                    }
+                    st = myrow[slotn];
+                    if (type == ZT_ICM) v0 = cm[st];
+                    else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st * 2); v0 = w.x; v1 = w.y; }
+                } else if (type == ZT_MATCH) {
+                    if (ma != 0) v0 = ht[wsub(mlimit, mb) & (i32)(ht_len - 1)];
+                } else if (type == ZT_MIX2) {
+                    cxt = (hctx + (c8 & (u32)cmask)) & (u32)(cc - 1);
+                    v0 = a16[cxt];
+                } else if (type == ZT_MIX) {
+                    cxt = (u32)(wadd((i32)hctx, (i32)c8 & cmask) & (cc - 1));
+                }
+                // ================= B. predictions in dependency order =================
+                if (type == ZT_CONST) pown = (ca - 128) * 16;
+                else if (type == ZT_CM) pown = stretch((i32)(v0 >> 17));
+                else if (type == ZT_ICM) pown = stretch((i32)(v0 >> 8));
+                else if (type == ZT_MATCH) {
+                    if (ma == 0) pown = 0;
+                    else {
+                        mc = (i32)((v0 >> (7u - mcxt)) & 1u);
+                        pown = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
+                    }
+                } else if (type == ZT_NONE || type > ZT_SSE) pown = 0;
+                if (act && (type <= ZT_MATCH || type > ZT_SSE)) P[lane] = pown;
+                for (int k = 0; k < cfg.ndep; k++) {
+                    const int ci = cfg.dep[k];
+                    const int ty = cfg.dep_type[k];
+                    if (ty == ZT_MIX) {
+                        // p = clamp2k(sum_l (w[l] >> 8) * p[j+l] >> 8): lane l takes weight l (predictor.v:600-614)
+                        const i32 j = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                        const i32 idx = (i32)__builtin_amdgcn_readlane((i32)cxt, ci) * m;
+                        const u32 *wm = reinterpret_cast<const u32 *>(slot + M.comp[ci].cm_off);
+                        i32 part = 0;
+                        for (i32 l = lane; l < m && (j + l) < n; l += 64) part = wadd(part, wmul((i32)wm[idx + l] >> 8, P[j + l]));
+                        for (int off = 32; off > 0; off >>= 1) part = wadd(part, __shfl_xor(part, off));
+                        if (lane == ci) { pown = clamp2k(part >> 8); P[ci] = pown; }
+                    } else if (lane == ci) {
+                        if (ty == ZT_AVG) {
+                            pown = (ca < n && cb < n) ? (wadd(wmul(P[ca], cc), wmul(P[cb], 256 - cc)) >> 8) : 0;
+                        } else if (ty == ZT_MIX2) {
+                            const i32 w = (i32)v0;
+                            pown = (cj < n && ck < n) ? clamp2k(wadd(wmul(w, P[cj]), wmul(65536 - w, P[ck])) >> 16) : 0;
+                        } else if (ty == ZT_ISSE) {
+                            const i32 w0 = (i32)v0, w1 = (i32)v1;
+                            pown = (cb < n) ? clamp2k(wadd(wmul(w0, P[cb]), wmul(w1, 64)) >> 16) : clamp2k(w1 >> 10);
+                        } else {                                   // SSE (predictor.v:632-659)
+                            const u32 cx = (hctx + c8) * 32u;
+                            i32 pq = 992;
+                            if (cb < n) pq = wadd(P[cb], 992);
+                            pq = min(max(pq, 0), 1983);
+                            const i32 wt = pq & 63;
+                            pq >>= 6;
+                            const i32 idx = wadd((i32)cx, pq), idx2 = wadd(idx, 1);
+                            if (idx >= 0 && idx2 < (i32)cm_len) {
+                                const i32 p1 = (i32)(cm[idx] >> 10), p2 = (i32)(cm[idx2] >> 10);
+                                pown = stretch(wadd(wmul(p1, 64 - wt), wmul(p2, wt)) >> 13);
+                            } else pown = 0;
+                            sse_idx = (u32)idx + (u32)(wt >> 5);
+                        }
+                        P[ci] = pown;
+                    }
+                }
+                // ================= C. code the bit on the last component's lane =================
+                const i32 sqown = squash(pown);
+                i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
+                if (lane == last) {
+                    const u32 p16 = (n == 0 ? 16384u : (u32)sqown) * 2u + 1u;
+                    const u32 mid = low + (u32)(((u64)(high - low) * p16) >> 16);
+                    if (DEC) y = code <= mid ? 1 : 0;
+                    if (y) high = mid; else low = mid + 1;
+                    while ((high ^ low) < 0x1000000u) {
+                        if (!DEC) { if (opos < cap) dst[opos] = (u8)(high >> 24); opos++; }
+                        low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+                        if (DEC) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
+                    }
+                }
+                if (DEC) y = __builtin_amdgcn_readlane(y, last);
+                // ================= D. every lane trains its component =================
+                const i32 t32767 = y ? 32767 : 0;
+                if (type == ZT_CM) {                               // predictor.v:681-700
+                    const i32 idx = (i32)cxt & (i32)(cm_len - 1);
+                    const i32 count = (i32)(v0 & 0x3ffu);
+                    const i32 err = t32767 - (i32)(v0 >> 17);
+                    const i32 upd = wmul(err, (i32)s_dt[count]) & -1024;
+                    cm[idx] = (u32)wadd(wadd((i32)v0, upd), count < climit ? 1 : 0);
+                } else if (type == ZT_ICM) {                       // predictor.v:701-709
+                    myrow[slotn] = s_ns[st * 4 + y];
+                    cm[st] = (u32)wadd((i32)v0, (t32767 - (i32)(v0 >> 8)) >> 2);
+                } else if (type == ZT_ISSE) {                      // predictor.v:776-791
+                    const i32 err = t32767 - sqown;
+                    if (cb < n) {
+                        const i32 w0 = clamp512k(wadd((i32)v0, wadd(wmul(err, P[cb]), 1 << 12) >> 13));
+                        const i32 w1 = clamp512k(wadd((i32)v1, (err + 16) >> 5));
+                        *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2((u32)w0, (u32)w1);
+                    }
+                    myrow[slotn] = s_ns[st * 4 + y];
+                } else if (type == ZT_MATCH) {                     // predictor.v:710-741
+                    const i32 mask = (i32)(ht_len - 1);
+                    if (mc != y) ma = 0;
+                    const i32 idx = mlimit & mask;
+                    ht[idx] = (u8)(((u32)ht[idx] << 1) | (u32)y);
+                    mcxt++;
+                    if (mcxt >= 8) {
+                        mcxt = 0;
+                        mlimit = wadd(mlimit, 1) & mask;
+                        const i32 ci = (i32)hctx & (i32)(cm_len - 1);
+                        if (ma == 0) {
+                            mb = wsub(mlimit, (i32)cm[ci]);
+                            if ((mb & mask) != 0) {
+                                while (ma < 255) {
+                                    const i32 i1 = wsub(wsub(mlimit, ma), 1) & mask;
+                                    const i32 i2 = wsub(wsub(wsub(mlimit, ma), mb), 1) & mask;
+                                    if (ht[i1] != ht[i2]) break;
+                                    ma++;
+                                }
+                            }
+                        } else if (ma < 255) ma++;
+                        cm[ci] = (u32)mlimit;
+                    }
+                } else if (type == ZT_MIX2) {                      // predictor.v:744-762
+                    const i32 err = wmul(t32767 - sqown, crate) >> 5;
+                    if (cj < n && ck < n) {
+                        i32 w = wadd((i32)v0, wadd(wmul(err, wsub(P[cj], P[ck])), 1 << 12) >> 13);
+                        w = min(max(w, 0), 65535);
+                        a16[cxt] = (u16)w;
+                    }
+                } else if (type == ZT_SSE) {                       // predictor.v:792-802
+                    const i32 idx = (i32)sse_idx & (i32)(cm_len - 1);
+                    u32 v = cm[idx];
+                    const i32 err = t32767 - (i32)(v >> 17);
+                    const i32 count = (i32)v & 1023;
+                    if (count < climit) v = (u32)wadd(wadd((i32)v, wadd(wmul(err, climit - count), 1 << 12) >> 13), 1);
+                    cm[idx] = v;
+                }
+                for (int k = 0; k < cfg.ndep; k++) {               // MIX: lane l trains weight l (predictor.v:763-775)
+                    if (cfg.dep_type[k] != ZT_MIX) continue;
+                    const int ci = cfg.dep[k];
+                    const i32 jj = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                    const i32 idx = (i32)__builtin_amdgcn_readlane((i32)cxt, ci) * m;
+                    const i32 err = __builtin_amdgcn_readlane(wmul(t32767 - sqown, crate) >> 4, ci);
+                    u32 *wm = reinterpret_cast<u32 *>(slot + M.comp[ci].cm_off);
+                    for (i32 l = lane; l < m && (jj + l) < n; l += 64)
+                        wm[idx + l] = (u32)clamp512k(wadd((i32)wm[idx + l], wadd(wmul(err, P[jj + l]), 1 << 12) >> 13));
+                    // a later bit may read these weights from other lanes
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                // ================= E. bit context (predictor.v:807-823) =================
+                c8 = (c8 << 1) | (u32)y;
+                const bool nib_end = (bit & 3) == 0;
+                if (nib_end && hashed && row_live) *reinterpret_cast<u32x4 *>(raddr) = *reinterpret_cast<const u32x4 *>(myrow);
+                if (c8 >= 256) {
+                    /* byte boundary handled below */
+                } else if (c8 >= 16 && c8 < 32) hmap4 = ((hmap4 & 0xfu) << 5) | ((u32)y << 4) | 1u;
+                else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
+            }
+            const u32 byte = c8 - 256;
+            // ---- ZPAQL.run(byte); h[i] = z.h[i] (predictor.v:809-816)
+            if (lane == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (act && (u32)lane < M.hlen) hctx = z.h[lane];
+            hmap4 = 1; c8 = 1;
+
+            if (DEC) {
+                if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
+                else {
+                    if (lane == last && opos < cap) dst[opos] = (u8)byte;
+                    opos++;
+                    if (opos > cap) break;
+                }
+            }
+        }
+        if (!DEC && lane == last) {                               // compress(-1) + flush (encoder.v:101-105,130-139)
+            high = low;
+            while ((high ^ low) < 0x1000000u) {
+                if (opos < cap) dst[opos] = (u8)(high >> 24);
+                opos++;
+                low <<= 8; high = (high << 8) | 255u; if (low == 0) low = 1;
+            }
+            for (int sft = 24; sft >= 0; sft -= 8) { if (opos < cap) dst[opos] = (u8)(high >> sft); opos++; }
+        }
+        const i32 st0 = __builtin_amdgcn_readlane(status, 0);
+        if (lane == last) {
+            i32 stt = st0;
+            if (opos > cap && stt == ZPQ_OK) stt = ZPQ_E_OVERFLOW;
+            B.out_len[blk] = opos;
+            B.status[blk] = stt;
+            if (DEC) {
+                if (B.consumed) B.consumed[blk] = ipos;
+                if (B.final_code) B.final_code[blk] = code;
+                if (B.first_byte) B.first_byte[blk] = first;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace zpql
+
+// ------------------------------------------------------------------ host side
+static bool lanes_cfg(const DModel *M, zpql::LCfg *cfg)
+{
+    if (M->n < 1 || M->n > 64) return false;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->n = M->n;
+    for (int i = 0; i < M->n; i++) {
+        const int t = M->comp[i].type;
+        if (t == ZT_AVG || t == ZT_MIX2 || t == ZT_MIX || t == ZT_ISSE || t == ZT_SSE) {
+            cfg->dep[cfg->ndep] = (uint8_t)i;
+            cfg->dep_type[cfg->ndep] = (uint8_t)t;
+            cfg->ndep++;
+        }
+    }
+    return true;
+}
+
+extern "C" int zpq_lanes_supported(const DModel *M)
+{
+    zpql::LCfg cfg;
+    return lanes_cfg(M, &cfg) ? 1 : 0;
+}
+
+extern "C" int zpq_lanes_blocks_per_cu(const DModel *)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)zpql::k_lanes<false>, 64 * zpql::WAVES,
+                                                     zpql::LDS_TOTAL) != hipSuccess || nb < 1)
+        nb = 2;
+    return nb * zpql::WAVES;
+}
+
+extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode, int nslots, hipStream_t stream)
+{
+    zpql::LCfg cfg;
+    if (!lanes_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
+    const int grid = (nslots + zpql::WAVES - 1) / zpql::WAVES;
+    if (decode) hipLaunchKernelGGL(zpql::k_lanes<true>, dim3(grid), dim3(64 * zpql::WAVES), zpql::LDS_TOTAL, stream, *B, cfg);
+    else hipLaunchKernelGGL(zpql::k_lanes<false>, dim3(grid), dim3(64 * zpql::WAVES), zpql::LDS_TOTAL, stream, *B, cfg);
+    return ZPQ_OK;
+}
