@@ -44,6 +44,14 @@ MODELS = {
     "sse": [[3, 16], [9, 8, 0, 32, 255]],
     "sse_out_of_table": [[3, 16], [9, 2, 0, 1, 2]],      # hashes far beyond the table: p = 0 (quirk Q10)
     "unknown_type": [[3, 12], [0], [8, 12, 0]],          # type 0 advances one byte (predictor.v:465-467)
+    # forward and self references feed the coded prediction: an input index >= the consumer's own index
+    # reads what that component predicted for the PREVIOUS bit (predictor.v:536-668 walks one p[] in order)
+    "fwd_avg": [[5, 1, 2, 100], [2, 12, 255], [3, 12], [6, 4, 0, 1, 24, 255]],
+    "fwd_isse": [[8, 12, 1], [3, 12], [5, 0, 1, 128]],
+    "fwd_mix_self": [[7, 4, 0, 3, 16, 255], [2, 12, 255], [3, 12], [5, 0, 2, 90]],
+    "fwd_sse_self": [[9, 4, 0, 32, 255], [3, 12], [5, 0, 1, 60]],
+    "fwd_mix2": [[6, 4, 1, 2, 20, 255], [1, 200], [4, 12, 12], [5, 0, 2, 128]],
+    "fwd_chain": [[8, 10, 3], [5, 0, 2, 77], [2, 10, 30], [9, 3, 1, 32, 100], [7, 2, 0, 4, 12, 3]],
 }
 
 

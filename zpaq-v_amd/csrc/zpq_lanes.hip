@@ -6,8 +6,10 @@
 // another component's prediction, so the ~35 dependent HBM loads per bit that the lane-0
 // interpreter (zpq_generic.hip) walks one after another are issued here by all lanes at once:
 //   A. every lane fetches its own component's state (CM slot, ICM/ISSE row + table entry,
-//      MATCH history byte, MIX2 weight) -- one memory latency for the whole model;
-//   B. predictions resolve in dependency order through an LDS array p[]: components without
+//      MATCH history byte, MIX2 weight), and all lanes together fetch the MIX weight vector (one
+//      weight per lane) and the SSE row (32 entries, one per lane) whose addresses also depend
+//      only on contexts -- one memory latency for the whole model;
+//   B. predictions resolve in dependency order, handed between lanes in registers: components without
 //      p-inputs (CONST/CM/ICM/MATCH) first, all together; then AVG/MIX2/ISSE/SSE one by one on
 //      their own lane, and MIX as a dot product over ALL lanes (lane l takes weight l) reduced
 //      with wavefront shuffles;
@@ -49,26 +51,48 @@ constexpr int L_DT = L_NS + 1024;                // u32[1024]
 constexpr int L_DT2K = L_DT + 4096;              // i16[256]
 constexpr int L_HDR = L_DT2K + 512;              // u8[ZPQ_MAX_HDR]
 constexpr int L_WAVE = L_HDR + ZPQ_MAX_HDR;      // per-wave scratch follows
-constexpr int W_P = 0;                           // i32 p[64]
-constexpr int W_ROW = 256;                       // u8 row[64][16]
-constexpr int W_BYTES = 256 + 1024;
+constexpr int W_ROW = 0;                         // u8 row[64][16]: the bit-history row each lane works in
+constexpr int W_H = 1024;                        // u32 H[<= 256]: the ZPAQL H array when it fits (else it stays in the slot)
+constexpr int W_H_WORDS = 256;
+constexpr int W_BYTES = 1024 + 4 * W_H_WORDS;
 constexpr int LDS_TOTAL = L_WAVE + WAVES * W_BYTES;
 
 // components whose prediction needs other components' predictions, in index order
 struct LCfg {
-    int32_t n, ndep;
-    uint8_t dep[64];
-    uint8_t dep_type[64];
+    int32_t n;
+    uint64_t depmask;            // bit i: component i consumes other predictions (AVG/MIX2/MIX/ISSE/SSE)
+    uint64_t mixmask;            // bit i: component i is a MIX
+    int32_t mix_ci[2];           // the first two MIX components: weights fetched with everything else (-1 = none)
+    int32_t sse_ci[2];           // the first two SSE components: whole 32-entry row fetched across lanes
+    int32_t has_isse, has_mix2;
 };
+
+// -DZPQ_LANES_PROF: per-phase s_memtime totals of block 0, printed at the end (diagnostic builds only)
+#ifdef ZPQ_LANES_PROF
+#define LPROF(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const u64 t_ = __builtin_readcyclecounter(); \
+                      prof[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define LPROF(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
+// sum over the 64 lanes: four DPP row shifts leave each row's total in its lane 15, then four v_readlane
+__device__ __forceinline__ i32 wave_sum(i32 x)
+{
+    x = wadd(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));   // row_shr:1
+    x = wadd(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));   // row_shr:2
+    x = wadd(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));   // row_shr:4
+    x = wadd(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));   // row_shr:8
+    return wadd(wadd(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
+                wadd(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
+}
 __device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
 __device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
 
 template <bool DEC>
-__global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg cfg)
+__global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const LCfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -93,7 +117,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
     const int16_t *s_dt2k = reinterpret_cast<const int16_t *>(lds + L_DT2K);
 
     const int lane = tid & 63, wave = tid >> 6;
-    i32 *P = reinterpret_cast<i32 *>(lds + L_WAVE + wave * W_BYTES + W_P);
+    u32 *hl = reinterpret_cast<u32 *>(lds + L_WAVE + wave * W_BYTES + W_H);
     u8 *myrow = lds + L_WAVE + wave * W_BYTES + W_ROW + lane * 16;
 
     const int n = cfg.n;
@@ -112,6 +136,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
     u8 *ht = slot + C.ht_off;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const bool hashed = type == ZT_ICM || type == ZT_ISSE;
+    const u32 cm_lo = (u32)(uintptr_t)cm, cm_hi = (u32)((u64)(uintptr_t)cm >> 32);
+    auto tab_of = [&](int ci) -> u32 * {                          // component ci's u32 table, wave-uniform
+        const u64 lo = (u32)__builtin_amdgcn_readlane((i32)cm_lo, ci), hi = (u32)__builtin_amdgcn_readlane((i32)cm_hi, ci);
+        return reinterpret_cast<u32 *>((uintptr_t)(lo | (hi << 32)));
+    };
 
     auto squash = [&](i32 d) -> i32 { return s_squash[min(max(wadd(d, 2047), 0), 4093)]; };      // predictor.v:193-202
     auto stretch = [&](i32 pr) -> i32 {                                                           // predictor.v:205-214
@@ -149,7 +178,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        P[lane] = 0;                                          // Predictor.p starts at 0 (predictor.v:326)
+        const bool h_in_lds = M.hlen <= (u32)W_H_WORDS;
+        if (h_in_lds) for (u32 i = lane; i < M.hlen; i += 64) hl[i] = 0;
         for (int k = 0; k < 4; k++) reinterpret_cast<u32 *>(myrow)[k] = 0;
 
         const u8 *src = B.in + B.in_off[blk];
@@ -161,21 +191,22 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
         Vm z;
         z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0;
         z.m = slot + M.m_off; z.mlen = M.mlen;
-        z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
+        z.h = h_in_lds ? hl : reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
         z.r = reinterpret_cast<u32 *>(slot + M.r_off);
         z.hdr = lds + L_HDR; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
 
         // per-lane component state
         u32 hctx = 0, cxt = 0, v0 = 0, v1 = 0, st = 0;
-        i32 pown = 0;
+        i32 pown = 0;                                         // Predictor.p starts at 0 (predictor.v:326)
         u8 *raddr = ht;
         bool row_live = false;
         // MATCH: a = len, b = offset, c = predicted bit, cxt = bit position, limit = buffer position.
         // Quirk: init leaves sizebits/bufbits in a/b (predictor.v:372-373,566-572).
         i32 ma = (type == ZT_MATCH) ? ca : 0, mb = (type == ZT_MATCH) ? cb : 0, mc = 0, mlimit = 0;
-        u32 mcxt = 0;
+        u32 mcxt = 0, mcur = 0;                               // mcur mirrors ht[limit], the byte being shifted in
         // SSE keeps both table entries it interpolated between
-        u32 sse_idx = 0;
+        u32 sse_idx = 0, sse_i0 = 0, sse_v0 = 0, sse_v1 = 0;
+        bool sse_ok = false;
 
         u32 c8 = 1, hmap4 = 1;
         u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, ipos = 0, first = 0xFFFFFFFFu;
@@ -184,6 +215,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
             for (int k = 0; k < 4; k++) { u32 c = 0; if (ipos < nin) c = src[ipos++]; code = (code << 8) | c; }
         const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
 
+#ifdef ZPQ_LANES_PROF
+        u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u64 tprev = __builtin_readcyclecounter();
+#endif
         for (u32 bi = 0; bi < total; bi++) {
             u32 ch = 0;
             if (!DEC) {
@@ -206,6 +241,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
             for (int bit = 7; bit >= 0; bit--) {
                 const bool nib = (c8 == 1) || ((c8 & 0xf0u) == 16u);
                 const u32 slotn = hmap4 & 15u;
+                LPROF(0);
                 // ================= A. every lane fetches its component's state =================
                 if (type == ZT_CM) {
                     cxt = hctx ^ hmap4;
@@ -241,8 +277,45 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                     v0 = a16[cxt];
                 } else if (type == ZT_MIX) {
                     cxt = (u32)(wadd((i32)hctx, (i32)c8 & cmask) & (cc - 1));
+                } else if (type == ZT_SSE) {
+                    cxt = (hctx + c8) * 32u;
                 }
+                // MIX weights (owner lane (idx + l) mod 64 takes weight l) and SSE rows: addresses known now
+                u32 pw0 = 0, pw1 = 0, sr0 = 0, sr1 = 0;
+                u32 *pa0 = nullptr, *pa1 = nullptr;
+                i32 pj0 = -1, pj1 = -1;
+                if (cfg.mix_ci[0] >= 0) {
+                    const int ci = cfg.mix_ci[0];
+                    const i32 j = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                    const i32 idx = wmul((i32)__builtin_amdgcn_readlane((i32)cxt, ci), m);
+                    const i32 l = (lane - idx) & 63;
+                    if (l < m && (j + l) < n) { pj0 = j + l; pa0 = tab_of(ci) + (idx + l); pw0 = *pa0; }
+                }
+                if (cfg.mix_ci[1] >= 0) {
+                    const int ci = cfg.mix_ci[1];
+                    const i32 j = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                    const i32 idx = wmul((i32)__builtin_amdgcn_readlane((i32)cxt, ci), m);
+                    const i32 l = (lane - idx) & 63;
+                    if (l < m && (j + l) < n) { pj1 = j + l; pa1 = tab_of(ci) + (idx + l); pw1 = *pa1; }
+                }
+                if (cfg.sse_ci[0] >= 0) {
+                    const int ci = cfg.sse_ci[0];
+                    const i32 il = wadd((i32)__builtin_amdgcn_readlane((i32)cxt, ci), lane);
+                    if (lane < 32 && il >= 0 && il < (i32)__builtin_amdgcn_readlane((i32)cm_len, ci)) sr0 = tab_of(ci)[il];
+                }
+                if (cfg.sse_ci[1] >= 0) {
+                    const int ci = cfg.sse_ci[1];
+                    const i32 il = wadd((i32)__builtin_amdgcn_readlane((i32)cxt, ci), lane);
+                    if (lane < 32 && il >= 0 && il < (i32)__builtin_amdgcn_readlane((i32)cm_len, ci)) sr1 = tab_of(ci)[il];
+                }
+                LPROF(1);
                 // ================= B. predictions in dependency order =================
+                // Predictions travel between lanes in registers (v_readlane with the consumer's wave-uniform
+                // input index; one bpermute for MIX's input vector) -- no LDS round trips in the chain.
+                // An input index >= the consumer's own index names a prediction not made yet this bit: the
+                // reference reads last bit's value there (predictor.v:536-668 walks i = 0..n-1 over one
+                // persistent p[]), so every lane keeps its previous prediction in pprev.
+                const i32 pprev = pown;
                 if (type == ZT_CONST) pown = (ca - 128) * 16;
                 else if (type == ZT_CM) pown = stretch((i32)(v0 >> 17));
                 else if (type == ZT_ICM) pown = stretch((i32)(v0 >> 8));
@@ -253,45 +326,78 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                         pown = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
                     }
                 } else if (type == ZT_NONE || type > ZT_SSE) pown = 0;
-                if (act && (type <= ZT_MATCH || type > ZT_SSE)) P[lane] = pown;
-                for (int k = 0; k < cfg.ndep; k++) {
-                    const int ci = cfg.dep[k];
-                    const int ty = cfg.dep_type[k];
+                i32 pin0 = 0, pin1 = 0;
+                for (u64 dm = cfg.depmask; dm != 0; dm &= dm - 1) {
+                    const int ci = __builtin_ctzll(dm);
+                    const int ty = __builtin_amdgcn_readlane(type, ci);
+                    auto inp = [&](int x) -> i32 {                 // x wave-uniform, < n
+                        return x < ci ? __builtin_amdgcn_readlane(pown, x) : __builtin_amdgcn_readlane(pprev, x);
+                    };
                     if (ty == ZT_MIX) {
-                        // p = clamp2k(sum_l (w[l] >> 8) * p[j+l] >> 8): lane l takes weight l (predictor.v:600-614)
-                        const i32 j = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
-                        const i32 idx = (i32)__builtin_amdgcn_readlane((i32)cxt, ci) * m;
-                        const u32 *wm = reinterpret_cast<const u32 *>(slot + M.comp[ci].cm_off);
-                        i32 part = 0;
-                        for (i32 l = lane; l < m && (j + l) < n; l += 64) part = wadd(part, wmul((i32)wm[idx + l] >> 8, P[j + l]));
-                        for (int off = 32; off > 0; off >>= 1) part = wadd(part, __shfl_xor(part, off));
-                        if (lane == ci) { pown = clamp2k(part >> 8); P[ci] = pown; }
-                    } else if (lane == ci) {
-                        if (ty == ZT_AVG) {
-                            pown = (ca < n && cb < n) ? (wadd(wmul(P[ca], cc), wmul(P[cb], 256 - cc)) >> 8) : 0;
-                        } else if (ty == ZT_MIX2) {
-                            const i32 w = (i32)v0;
-                            pown = (cj < n && ck < n) ? clamp2k(wadd(wmul(w, P[cj]), wmul(65536 - w, P[ck])) >> 16) : 0;
-                        } else if (ty == ZT_ISSE) {
+                        // p = clamp2k(sum_l (w[l] >> 8) * p[j+l] >> 8) (predictor.v:600-614)
+                        const i32 merged = lane < ci ? pown : pprev;
+                        i32 part;
+                        if (ci == cfg.mix_ci[0]) {
+                            const i32 t = __shfl(merged, pj0 & 63);
+                            pin0 = pj0 >= 0 ? t : 0;
+                            part = wmul((i32)pw0 >> 8, pin0);
+                        } else if (ci == cfg.mix_ci[1]) {
+                            const i32 t = __shfl(merged, pj1 & 63);
+                            pin1 = pj1 >= 0 ? t : 0;
+                            part = wmul((i32)pw1 >> 8, pin1);
+                        } else {                                   // third and later MIX: weights fetched here
+                            const i32 j = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                            const i32 idx = wmul((i32)__builtin_amdgcn_readlane((i32)cxt, ci), m);
+                            const i32 l = (lane - idx) & 63;
+                            const bool mine = l < m && (j + l) < n;
+                            const i32 t = __shfl(merged, (j + l) & 63);
+                            part = mine ? wmul((i32)tab_of(ci)[idx + l] >> 8, t) : 0;
+                        }
+                        const i32 sum = wave_sum(part);
+                        if (lane == ci) pown = clamp2k(sum >> 8);
+                    } else if (ty == ZT_AVG) {                     // predictor.v:590-594
+                        const i32 xa = __builtin_amdgcn_readlane(ca, ci), xb = __builtin_amdgcn_readlane(cb, ci);
+                        const bool ok = xa < n && xb < n;
+                        const i32 ia = ok ? inp(xa) : 0, ib = ok ? inp(xb) : 0;
+                        if (lane == ci) pown = ok ? (wadd(wmul(ia, cc), wmul(ib, 256 - cc)) >> 8) : 0;
+                    } else if (ty == ZT_MIX2) {                    // predictor.v:595-599
+                        const i32 xj = __builtin_amdgcn_readlane(cj, ci), xk = __builtin_amdgcn_readlane(ck, ci);
+                        const bool ok = xj < n && xk < n;
+                        const i32 ij = ok ? inp(xj) : 0, ik = ok ? inp(xk) : 0;
+                        if (lane == ci) { const i32 w = (i32)v0; pown = ok ? clamp2k(wadd(wmul(w, ij), wmul(65536 - w, ik)) >> 16) : 0; }
+                    } else if (ty == ZT_ISSE) {                    // predictor.v:615-631
+                        const i32 xb = __builtin_amdgcn_readlane(cb, ci);
+                        const bool ok = xb < n;
+                        const i32 ib = ok ? inp(xb) : 0;
+                        if (lane == ci) {
                             const i32 w0 = (i32)v0, w1 = (i32)v1;
-                            pown = (cb < n) ? clamp2k(wadd(wmul(w0, P[cb]), wmul(w1, 64)) >> 16) : clamp2k(w1 >> 10);
-                        } else {                                   // SSE (predictor.v:632-659)
-                            const u32 cx = (hctx + c8) * 32u;
-                            i32 pq = 992;
-                            if (cb < n) pq = wadd(P[cb], 992);
-                            pq = min(max(pq, 0), 1983);
-                            const i32 wt = pq & 63;
-                            pq >>= 6;
-                            const i32 idx = wadd((i32)cx, pq), idx2 = wadd(idx, 1);
-                            if (idx >= 0 && idx2 < (i32)cm_len) {
-                                const i32 p1 = (i32)(cm[idx] >> 10), p2 = (i32)(cm[idx2] >> 10);
-                                pown = stretch(wadd(wmul(p1, 64 - wt), wmul(p2, wt)) >> 13);
+                            pown = ok ? clamp2k(wadd(wmul(w0, ib), wmul(w1, 64)) >> 16) : clamp2k(w1 >> 10);
+                        }
+                    } else {                                       // SSE (predictor.v:632-659)
+                        const i32 xb = __builtin_amdgcn_readlane(cb, ci);
+                        i32 pq = 992;
+                        if (xb < n) pq = wadd(inp(xb), 992);
+                        pq = min(max(pq, 0), 1983);
+                        const i32 wt = pq & 63;
+                        pq >>= 6;
+                        const bool pre0 = ci == cfg.sse_ci[0], pre1 = ci == cfg.sse_ci[1];
+                        // prefetched row: entry e sits in lane e
+                        const u32 srow = pre0 ? sr0 : sr1;
+                        const u32 e0 = (u32)__builtin_amdgcn_readlane((i32)srow, pq), e1 = (u32)__builtin_amdgcn_readlane((i32)srow, pq + 1);
+                        if (lane == ci) {
+                            const i32 idx = wadd((i32)cxt, pq), idx2 = wadd(idx, 1);
+                            sse_ok = idx >= 0 && idx2 < (i32)cm_len;
+                            if (sse_ok) {
+                                sse_i0 = (u32)idx;
+                                if (pre0 || pre1) { sse_v0 = e0; sse_v1 = e1; }
+                                else { sse_v0 = cm[idx]; sse_v1 = cm[idx2]; }
+                                pown = stretch(wadd(wmul((i32)(sse_v0 >> 10), 64 - wt), wmul((i32)(sse_v1 >> 10), wt)) >> 13);
                             } else pown = 0;
                             sse_idx = (u32)idx + (u32)(wt >> 5);
                         }
-                        P[ci] = pown;
                     }
                 }
+                LPROF(2);
                 // ================= C. code the bit on the last component's lane =================
                 const i32 sqown = squash(pown);
                 i32 y = DEC ? 0 : (i32)((ch >> bit) & 1u);
@@ -307,8 +413,13 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                     }
                 }
                 if (DEC) y = __builtin_amdgcn_readlane(y, last);
+                LPROF(3);
                 // ================= D. every lane trains its component =================
                 const i32 t32767 = y ? 32767 : 0;
+                // training reads the finished predictions of this bit (predictor.v:672-824 runs after predict)
+                const i32 fin_b = cfg.has_isse ? __shfl(pown, cb & 63) : 0;
+                const i32 fin_j = cfg.has_mix2 ? __shfl(pown, cj & 63) : 0;
+                const i32 fin_k = cfg.has_mix2 ? __shfl(pown, ck & 63) : 0;
                 if (type == ZT_CM) {                               // predictor.v:681-700
                     const i32 idx = (i32)cxt & (i32)(cm_len - 1);
                     const i32 count = (i32)(v0 & 0x3ffu);
@@ -321,7 +432,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                 } else if (type == ZT_ISSE) {                      // predictor.v:776-791
                     const i32 err = t32767 - sqown;
                     if (cb < n) {
-                        const i32 w0 = clamp512k(wadd((i32)v0, wadd(wmul(err, P[cb]), 1 << 12) >> 13));
+                        const i32 w0 = clamp512k(wadd((i32)v0, wadd(wmul(err, fin_b), 1 << 12) >> 13));
                         const i32 w1 = clamp512k(wadd((i32)v1, (err + 16) >> 5));
                         *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2((u32)w0, (u32)w1);
                     }
@@ -330,11 +441,13 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                     const i32 mask = (i32)(ht_len - 1);
                     if (mc != y) ma = 0;
                     const i32 idx = mlimit & mask;
-                    ht[idx] = (u8)(((u32)ht[idx] << 1) | (u32)y);
+                    mcur = ((mcur << 1) | (u32)y) & 255u;
+                    ht[idx] = (u8)mcur;
                     mcxt++;
                     if (mcxt >= 8) {
                         mcxt = 0;
                         mlimit = wadd(mlimit, 1) & mask;
+                        mcur = ht[mlimit];
                         const i32 ci = (i32)hctx & (i32)(cm_len - 1);
                         if (ma == 0) {
                             mb = wsub(mlimit, (i32)cm[ci]);
@@ -352,32 +465,41 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                 } else if (type == ZT_MIX2) {                      // predictor.v:744-762
                     const i32 err = wmul(t32767 - sqown, crate) >> 5;
                     if (cj < n && ck < n) {
-                        i32 w = wadd((i32)v0, wadd(wmul(err, wsub(P[cj], P[ck])), 1 << 12) >> 13);
+                        i32 w = wadd((i32)v0, wadd(wmul(err, wsub(fin_j, fin_k)), 1 << 12) >> 13);
                         w = min(max(w, 0), 65535);
                         a16[cxt] = (u16)w;
                     }
                 } else if (type == ZT_SSE) {                       // predictor.v:792-802
                     const i32 idx = (i32)sse_idx & (i32)(cm_len - 1);
-                    u32 v = cm[idx];
+                    // the trained entry is one of the two just interpolated whenever the index was in range
+                    u32 v;
+                    if (sse_ok && (u32)idx == sse_i0) v = sse_v0;
+                    else if (sse_ok && (u32)idx == sse_i0 + 1u) v = sse_v1;
+                    else v = cm[idx];
                     const i32 err = t32767 - (i32)(v >> 17);
                     const i32 count = (i32)v & 1023;
                     if (count < climit) v = (u32)wadd(wadd((i32)v, wadd(wmul(err, climit - count), 1 << 12) >> 13), 1);
                     cm[idx] = v;
                 }
-                for (int k = 0; k < cfg.ndep; k++) {               // MIX: lane l trains weight l (predictor.v:763-775)
-                    if (cfg.dep_type[k] != ZT_MIX) continue;
-                    const int ci = cfg.dep[k];
-                    const i32 jj = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
-                    const i32 idx = (i32)__builtin_amdgcn_readlane((i32)cxt, ci) * m;
+                for (u64 dm = cfg.mixmask; dm != 0; dm &= dm - 1) {   // MIX: the owner lane trains its weight (predictor.v:763-775)
+                    const int ci = __builtin_ctzll(dm);
                     const i32 err = __builtin_amdgcn_readlane(wmul(t32767 - sqown, crate) >> 4, ci);
-                    u32 *wm = reinterpret_cast<u32 *>(slot + M.comp[ci].cm_off);
-                    for (i32 l = lane; l < m && (jj + l) < n; l += 64)
-                        wm[idx + l] = (u32)clamp512k(wadd((i32)wm[idx + l], wadd(wmul(err, P[jj + l]), 1 << 12) >> 13));
-                    // a later bit may read these weights from other lanes
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (ci == cfg.mix_ci[0]) {
+                        const i32 fin = __shfl(pown, pj0 & 63);
+                        if (pj0 >= 0) *pa0 = (u32)clamp512k(wadd((i32)pw0, wadd(wmul(err, fin), 1 << 12) >> 13));
+                    } else if (ci == cfg.mix_ci[1]) {
+                        const i32 fin = __shfl(pown, pj1 & 63);
+                        if (pj1 >= 0) *pa1 = (u32)clamp512k(wadd((i32)pw1, wadd(wmul(err, fin), 1 << 12) >> 13));
+                    } else {
+                        const i32 jj = __builtin_amdgcn_readlane(cb, ci), m = __builtin_amdgcn_readlane(climit, ci);
+                        const i32 idx = wmul((i32)__builtin_amdgcn_readlane((i32)cxt, ci), m);
+                        const i32 l = (lane - idx) & 63;                // same owner lane as in predict
+                        const i32 fin = __shfl(pown, (jj + l) & 63);
+                        u32 *wm = tab_of(ci);
+                        if (l < m && (jj + l) < n) wm[idx + l] = (u32)clamp512k(wadd((i32)wm[idx + l], wadd(wmul(err, fin), 1 << 12) >> 13));
+                    }
                 }
+                LPROF(4);
                 // ================= E. bit context (predictor.v:807-823) =================
                 c8 = (c8 << 1) | (u32)y;
                 const bool nib_end = (bit & 3) == 0;
@@ -387,6 +509,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
                 } else if (c8 >= 16 && c8 < 32) hmap4 = ((hmap4 & 0xfu) << 5) | ((u32)y << 4) | 1u;
                 else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
             }
+            LPROF(5);
             const u32 byte = c8 - 256;
             // ---- ZPAQL.run(byte); h[i] = z.h[i] (predictor.v:809-816)
             if (lane == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
@@ -395,6 +518,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (act && (u32)lane < M.hlen) hctx = z.h[lane];
             hmap4 = 1; c8 = 1;
+            LPROF(6);
 
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
@@ -414,6 +538,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_lanes(const DBatch B, const LCfg
             }
             for (int sft = 24; sft >= 0; sft -= 8) { if (opos < cap) dst[opos] = (u8)(high >> sft); opos++; }
         }
+#ifdef ZPQ_LANES_PROF
+        if (blk == 0 && lane == 0)
+            printf("LPROF %s eof/other=%llu A=%llu B=%llu C=%llu D=%llu E=%llu vm=%llu\n", DEC ? "dec" : "enc",
+                   (unsigned long long)prof[0], (unsigned long long)prof[1], (unsigned long long)prof[2], (unsigned long long)prof[3],
+                   (unsigned long long)prof[4], (unsigned long long)prof[5], (unsigned long long)prof[6]);
+#endif
         const i32 st0 = __builtin_amdgcn_readlane(status, 0);
         if (lane == last) {
             i32 stt = st0;
@@ -439,13 +569,15 @@ static bool lanes_cfg(const DModel *M, zpql::LCfg *cfg)
     if (M->n < 1 || M->n > 64) return false;
     memset(cfg, 0, sizeof *cfg);
     cfg->n = M->n;
+    cfg->mix_ci[0] = cfg->mix_ci[1] = cfg->sse_ci[0] = cfg->sse_ci[1] = -1;
+    int nmix = 0, nsse = 0;
     for (int i = 0; i < M->n; i++) {
         const int t = M->comp[i].type;
-        if (t == ZT_AVG || t == ZT_MIX2 || t == ZT_MIX || t == ZT_ISSE || t == ZT_SSE) {
-            cfg->dep[cfg->ndep] = (uint8_t)i;
-            cfg->dep_type[cfg->ndep] = (uint8_t)t;
-            cfg->ndep++;
-        }
+        if (t == ZT_AVG || t == ZT_MIX2 || t == ZT_MIX || t == ZT_ISSE || t == ZT_SSE) cfg->depmask |= 1ull << i;
+        if (t == ZT_MIX) { cfg->mixmask |= 1ull << i; if (nmix < 2) cfg->mix_ci[nmix++] = i; }
+        if (t == ZT_SSE && nsse < 2) cfg->sse_ci[nsse++] = i;
+        if (t == ZT_ISSE) cfg->has_isse = 1;
+        if (t == ZT_MIX2) cfg->has_mix2 = 1;
     }
     return true;
 }
