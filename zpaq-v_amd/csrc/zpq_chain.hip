@@ -31,6 +31,7 @@
 #include "../../include/zpaq_hip.h"
 #include "zpq_common.h"
 #include "zpq_vm.h"
+#include "zpq_host.h"
 
 // Measured on MI355X at two waves per SIMD (profiles/r01): the pipelined step wins for
 // encode (364 vs 373 ms), the plain one for decode (427 vs 456 ms).
@@ -731,12 +732,7 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     const uint8_t *p = M->header + M->hbegin;
     const int plen = M->hend - M->hbegin;
     {
-        std::vector<uint8_t> want = {74, 18, 104, 95, 0};
-        for (int k = 0; k < M->n - 1; k++) { want.push_back(59); want.push_back(112); want.push_back(25); }
-        want.push_back(59); want.push_back(112); want.push_back(56);
-        if (plen == (int)want.size() && memcmp(p, want.data(), want.size()) == 0 && M->mlen >= 2 &&
-            M->hlen >= (uint32_t)M->n)
-            cfg->vm_kind = zpqc::VM_HASHCHAIN;
+        if (zpq_vm_hashchain(M) == M->n) cfg->vm_kind = zpqc::VM_HASHCHAIN;
         static const uint8_t l1[] = {96, 4, 28, 59, 10, 59, 112, 25, 10, 59, 10, 59, 112, 56};
         if (plen == (int)sizeof l1 && memcmp(p, l1, sizeof l1) == 0 && M->mlen == 4 && M->hlen == 2 && M->n == 2)
             cfg->vm_kind = zpqc::VM_LEVEL1;

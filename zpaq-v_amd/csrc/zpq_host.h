@@ -26,6 +26,12 @@ uint64_t tables_fnv(int which);
 // ICM/ISSE hash table that is at least 2x larger than the store; false if none qualifies.
 bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out);
 
+// The HCOMP shape every shipped level >= 2 uses (levels.v:126-141 and on):
+//   b=c c-- *c=a d=0 (hash *d=a d++) x K  hash *d=a halt
+// leaves H[k] = hash^(k+1)(byte, previous byte) for k <= K and never touches H beyond.  Returns the
+// number of hashes K+1 when the model's program is exactly that (and M, H are large enough), else 0.
+int zpq_vm_hashchain(const DModel *M);
+
 struct zpq_model {
     DModel d;
     std::vector<uint32_t> img;  // initial table contents (ICM/ISSE/SSE), uploaded per ctx

@@ -31,6 +31,7 @@
 #include "../../include/zpaq_hip.h"
 #include "zpq_common.h"
 #include "zpq_vm.h"
+#include "zpq_host.h"
 
 namespace zpql {
 
@@ -65,6 +66,7 @@ struct LCfg {
     int32_t mix_ci[2];           // the first two MIX components: weights fetched with everything else (-1 = none)
     int32_t sse_ci[2];           // the first two SSE components: whole 32-entry row fetched across lanes
     int32_t has_isse, has_mix2;
+    int32_t vm_hashes;           // > 0: the program is the shipped hash chain (zpq_vm_hashchain), evaluated in registers
 };
 
 // -DZPQ_LANES_PROF: per-phase s_memtime totals of block 0, printed at the end (diagnostic builds only)
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
         u32 sse_idx = 0, sse_i0 = 0, sse_v0 = 0, sse_v1 = 0;
         bool sse_ok = false;
 
-        u32 c8 = 1, hmap4 = 1;
+        u32 c8 = 1, hmap4 = 1, vm_prev = 0;
         u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, ipos = 0, first = 0xFFFFFFFFu;
         bool got_first = false;
         if (DEC && lane == last)
@@ -512,11 +514,20 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
             LPROF(5);
             const u32 byte = c8 - 256;
             // ---- ZPAQL.run(byte); h[i] = z.h[i] (predictor.v:809-816)
-            if (lane == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (act && (u32)lane < M.hlen) hctx = z.h[lane];
+            if (cfg.vm_hashes > 0) {
+                // H[k] = hash^(k+1)(byte, previous byte), hash: a = (a + *b + 512) * 773 (zpaql.v HASH);
+                // every lane walks the chain and keeps its own link
+                u32 a = byte, hv = 0;
+                for (int k = 0; k < cfg.vm_hashes; k++) { a = (a + vm_prev + 512u) * 773u; hv = (k == lane) ? a : hv; }
+                vm_prev = byte;
+                if (act) hctx = hv;
+            } else {
+                if (lane == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (act && (u32)lane < M.hlen) hctx = z.h[lane];
+            }
             hmap4 = 1; c8 = 1;
             LPROF(6);
 
@@ -579,6 +590,7 @@ static bool lanes_cfg(const DModel *M, zpql::LCfg *cfg)
         if (t == ZT_ISSE) cfg->has_isse = 1;
         if (t == ZT_MIX2) cfg->has_mix2 = 1;
     }
+    cfg->vm_hashes = zpq_vm_hashchain(M);
     return true;
 }
 

@@ -469,6 +469,22 @@ extern "C" int zpq_model_create_level(int level, zpq_model **out)
 
 extern "C" void zpq_model_destroy(zpq_model *m) { delete m; }
 extern "C" int zpq_model_ncomp(const zpq_model *m) { return m ? m->d.n : 0; }
+int zpq_vm_hashchain(const DModel *M)
+{
+    static const uint8_t head[] = {74, 18, 104, 95, 0}, tail[] = {59, 112, 56};
+    const uint8_t *p = M->header + M->hbegin;
+    const int plen = M->hend - M->hbegin;
+    if (plen < (int)(sizeof head + sizeof tail) || (plen - (int)(sizeof head + sizeof tail)) % 3 != 0) return 0;
+    if (memcmp(p, head, sizeof head) != 0 || memcmp(p + plen - sizeof tail, tail, sizeof tail) != 0) return 0;
+    const int K = (plen - (int)(sizeof head + sizeof tail)) / 3;
+    for (int k = 0; k < K; k++) {
+        const uint8_t *q = p + sizeof head + 3 * k;
+        if (q[0] != 59 || q[1] != 112 || q[2] != 25) return 0;
+    }
+    if (M->mlen < 2 || M->hlen < (uint32_t)(K + 1)) return 0;
+    return K + 1;
+}
+
 extern "C" uint64_t zpq_model_state_bytes(const zpq_model *m) { return m ? m->d.slot_bytes : 0; }
 extern "C" int zpq_model_has_fast_path(const zpq_model *m) { return m ? (int)m->d.fast_kind : 0; }
 
