@@ -62,6 +62,14 @@ private:
     bool final_;
 };
 
+// The framing bytes around a coded payload, shared by Compressor and the batch archive writer.
+namespace framing {
+void block_header(Writer &w, const uint8_t *hdr, int len, int cend, int hbegin, int hend);   // compressor.v:63-75,150-181
+void segment_header(Writer &w, const std::string &filename, const std::string &comment);     // compressor.v:217-235
+void segment_trailer(Writer &w, const uint8_t sha1[20]);       // 00 00 00 00, 253, digest   // compressor.v:382-395
+void block_end(Writer &w);                                                                   // compressor.v:407-410
+}
+
 // compressor.v:16-418
 class Compressor {
 public:
@@ -114,6 +122,8 @@ public:
     void read_segment_end();                                       // :590-635
     std::vector<uint8_t> get_sha1() { return sha1_.result(); }
     int last_error() const { return err_; }
+    // digest stored behind marker 253 of the segment just ended (the reference reads and drops it, :608-628)
+    bool stored_sha1(uint8_t out20[20]) const { if (has_stored_sha1_) for (int i = 0; i < 20; i++) out20[i] = stored_sha1_[i]; return has_stored_sha1_; }
 private:
     int get();
     bool decompress_store(int n);
@@ -142,7 +152,29 @@ private:
     uint32_t final_code_;
     int segs_in_block_;
     int err_;
+    bool has_stored_sha1_;
+    uint8_t stored_sha1_[20];
 };
+
+// ---- batch form of the reference CLI's loops (cmd/main.v:239-470) -------------------------------
+// The CLI writes ONE BLOCK WITH ONE SEGMENT PER FILE (cmd/main.v:283-311), and blocks are
+// independent, so a set of files is a batch: all blocks are coded by one zpq_encode_blocks call
+// (and hashed by one zpq_sha1_blocks call) instead of a Compressor per file.  The archive bytes
+// are identical to what the per-file Compressor loop writes.
+struct ArchiveFile {
+    std::string name, comment;
+    std::vector<uint8_t> data;
+    uint64_t size = 0;        // uncompressed bytes (filled by archive_extract even when data is not wanted)
+    bool sha1_ok = true;      // stored digest == digest of the extracted bytes (the reference reads it and ignores it, decompressor.v:608-628)
+    int status = ZPQ_OK;      // per-file ZPQ_* code
+};
+// run_add (cmd/main.v:283-311): appends one block per file to *archive.  level 0..5.
+int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive);
+// run_extract / run_list (cmd/main.v:342-380,440-465): every segment of every block, in archive
+// order.  Single-segment modelled blocks are decoded together in one batch; anything else
+// (store mode, several segments per block) goes through Decompresser.  want_data = false keeps
+// only names, comments and sizes (list).
+int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files);
 
 }  // namespace zpaq
 
@@ -174,4 +206,19 @@ void zpqf_decompresser_read_segment_end(zpqf_decomp *);
 int zpqf_decompresser_last_error(zpqf_decomp *);
 size_t zpqf_decompresser_output(zpqf_decomp *, const uint8_t **p);
 void zpqf_decompresser_sha1(zpqf_decomp *, uint8_t out20[20]);
+/* archive_add / archive_extract for ctypes: names/comments are NUL-terminated, data[i] has lens[i] bytes.
+ * The result lives in the returned handle until zpqf_archive_free. */
+struct zpqf_archive;
+zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
+                               const uint8_t *const *data, const uint64_t *lens, int *rc);
+size_t zpqf_archive_bytes(zpqf_archive *, const uint8_t **p);
+zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data, int *rc);
+int zpqf_archive_nfiles(zpqf_archive *);
+const char *zpqf_archive_name(zpqf_archive *, int i);
+const char *zpqf_archive_comment(zpqf_archive *, int i);
+uint64_t zpqf_archive_size(zpqf_archive *, int i);
+int zpqf_archive_sha1_ok(zpqf_archive *, int i);
+int zpqf_archive_status(zpqf_archive *, int i);
+const uint8_t *zpqf_archive_data(zpqf_archive *, int i);
+void zpqf_archive_free(zpqf_archive *);
 }

@@ -72,6 +72,7 @@ int zpq_ctx_create(int device, zpq_ctx **out);
 void zpq_ctx_destroy(zpq_ctx *);
 int zpq_ctx_sync(zpq_ctx *);
 void *zpq_ctx_stream(zpq_ctx *); /* the hipStream_t all launches of this ctx go to */
+int zpq_ctx_device(const zpq_ctx *); /* HIP device index the ctx was created on */
 /* Upper bound on state-slot memory this ctx may hold (default: 75% of free HBM). */
 int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
 /* Largest block (bytes) the caller will submit to the chain kernel for models with huge hash
@@ -123,6 +124,19 @@ int zpq_decode_blocks_dev(zpq_ctx *, const zpq_model *, int nblocks, const uint8
                           const uint64_t *in_off, uint32_t flags, uint8_t *out,
                           const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
                           uint32_t *final_code, uint32_t *first_byte, int32_t *status);
+
+/*
+ * SHA-1 of nblocks independent byte ranges in[in_off[b] .. in_off[b+1]) -> out20[20*b ..]:
+ * the digest Compressor/Decompresser accumulate with sha1.put() per uncompressed byte
+ * (compressor.v:284, decompressor.v:493,505; sha1.v:6-146) and store behind marker 253 in the
+ * segment trailer (compressor.v:389-395).  One message per GPU lane, so it pays for batches
+ * (hundreds of ranges); a front end handling a single large segment should hash on the host.
+ * _dev: device pointers, enqueue only on the ctx stream.  zpq_sha1_ranges_dev takes explicit
+ * [begin[b], end[b]) pairs (decoded blocks sit in capacity-strided slabs).
+ */
+int zpq_sha1_ranges_dev(zpq_ctx *, int nranges, const uint8_t *in, const uint64_t *begin, const uint64_t *end, uint8_t *out20);
+int zpq_sha1_blocks(zpq_ctx *, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20);
+int zpq_sha1_blocks_dev(zpq_ctx *, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20);
 
 /*
  * One ZPAQ block whose model state persists across segments -- what

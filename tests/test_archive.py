@@ -1,0 +1,176 @@
+"""Batch archive layer (zpaq::archive_add / archive_extract, include/zpaq_frontend.hpp) and the SHA-1
+side kernel: the reference CLI's add / extract / list loops (cmd/main.v:239-470) with all files of a
+call coded as one GPU batch.  Archives must be byte-identical to the per-file Compressor loop, which
+the oracle's framing writer (zo_compress_archive, oracle/zpaq_oracle.c) restates."""
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import oracle_lib as O  # noqa: E402
+from inputs import INPUTS  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "zpaq-v_amd", "bin", "zpaqv")
+
+
+def file_set(seed=7, n=40):
+    rnd = random.Random(seed)
+    files = [("empty", b""), ("one", b"x"), ("hello.txt", b"Hello World!"), ("zeros", bytes(3000)),
+             ("text", INPUTS["text2k"]), ("lcg", INPUTS["lcg4k"])]
+    for i in range(n):
+        k = rnd.choice([1, 17, 63, 64, 65, 500, 4096, 9000])
+        kind = i % 3
+        if kind == 0:
+            d = bytes(rnd.getrandbits(8) for _ in range(k))
+        elif kind == 1:
+            d = (b"abcabcabd" * (k // 9 + 1))[:k]
+        else:
+            d = bytes((j * 7 + i) & 63 | 32 for j in range(k))
+        files.append(("f%03d.bin" % i, d))
+    return [(nm, "%d bytes" % len(d), d) for nm, d in files]
+
+
+def oracle_one(level, name, comment, data):
+    out = C.create_string_buffer(len(data) * 17 + 70000)
+    n = O.lib().zo_compress_archive(level, name.encode(), comment.encode(), data, len(data), 1, out, len(out))
+    assert n > 0
+    return out.raw[:n]
+
+
+def oracle_archive(level, files):
+    return b"".join(oracle_one(level, nm, cm, d) for nm, cm, d in files)
+
+
+# ---------------------------------------------------------------- CPU: store mode needs no GPU
+def test_store_mode_batch_archive_equals_oracle_and_round_trips(zpq):
+    files = file_set(n=6)
+    arc = zpq.archive_add(None, 0, files)
+    assert arc == oracle_archive(0, files)
+    got = zpq.archive_extract(None, arc)
+    assert [(g["name"], g["comment"], g["data"]) for g in got] == files
+    assert all(g["sha1_ok"] and g["status"] == 0 for g in got)
+    listed = zpq.archive_extract(None, arc, want_data=False)
+    assert [(g["name"], g["size"]) for g in listed] == [(nm, len(d)) for nm, _, d in files]
+
+
+def test_modelled_level_without_a_device_fails_loudly(zpq):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(zpq.ZpqError):
+        zpq.archive_add(None, 2, file_set(n=1))
+
+
+def test_cli_store_mode_round_trip(tmp_path):
+    src = tmp_path / "in"
+    (src / "sub").mkdir(parents=True)
+    (src / "a.txt").write_bytes(b"hello world\n")
+    (src / "sub" / "r.bin").write_bytes(INPUTS["lcg4k"])
+    (src / "empty").write_bytes(b"")
+    arc = str(tmp_path / "arc")
+    r = subprocess.run([CLI, "a", arc, str(src), "-m0", "-s1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files added: 3" in r.stdout, r.stderr
+    r = subprocess.run([CLI, "l", arc], capture_output=True, text=True)
+    assert "r.bin (4096 bytes)" in r.stdout and "Total files: 3" in r.stdout
+    out = tmp_path / "out"
+    r = subprocess.run([CLI, "x", arc, "-to", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files extracted: 3" in r.stdout, r.stderr
+    assert (out / "r.bin").read_bytes() == INPUTS["lcg4k"] and (out / "a.txt").read_bytes() == b"hello world\n"
+    r = subprocess.run([CLI, "x", arc, "-to", str(out)], capture_output=True, text=True)      # no -force: skipped
+    assert "Files extracted: 0" in r.stdout and "exists, skipping" in r.stderr
+    r = subprocess.run([CLI, "x", arc, "-test", "-only", "*.txt"], capture_output=True, text=True)
+    assert "Verified: a.txt" in r.stdout and "Files verified: 1" in r.stdout
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_sha1_side_kernel_matches_hashlib(gpu_ctx):
+    rnd = random.Random(3)
+    lens = [0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1000, 4095, 65536, 70001] + \
+           [rnd.randint(0, 300) for _ in range(150)]
+    blocks = [bytes(rnd.getrandbits(8) for _ in range(k)) for k in lens]      # contiguous: every alignment occurs
+    got = gpu_ctx.sha1_blocks(blocks)
+    assert got == [hashlib.sha1(b).digest() for b in blocks]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_batch_archive_equals_per_file_oracle_archive(zpq, gpu_ctx, level):
+    files = file_set(seed=level)
+    arc = zpq.archive_add(gpu_ctx, level, files)
+    assert arc == oracle_archive(level, files)
+    got = zpq.archive_extract(gpu_ctx, arc)
+    assert [(g["name"], g["comment"], g["data"]) for g in got] == files
+    assert all(g["sha1_ok"] and g["status"] == 0 for g in got)
+    listed = zpq.archive_extract(gpu_ctx, arc, want_data=False)
+    assert [(g["name"], g["size"]) for g in listed] == [(nm, len(d)) for nm, _, d in files]
+
+
+@pytest.mark.gpu
+def test_extract_mixed_archive_levels_store_and_multi_segment_blocks(zpq, gpu_ctx):
+    files = file_set(seed=11, n=9)
+    parts = [zpq.archive_add(gpu_ctx, 2, files[:5]), zpq.archive_add(None, 0, files[5:8]), zpq.archive_add(gpu_ctx, 1, files[8:12])]
+    # one block holding two segments, written by the sequential front end
+    c = zpq.Compressor(gpu_ctx)
+    c.start_block(2)
+    for nm, cm, d in files[12:14]:
+        c.start_segment(nm, cm)
+        c.set_input(d)
+        while c.compress(65536):
+            pass
+        c.end_segment()
+    c.end_block()
+    parts.append(c.output_bytes())
+    parts.append(zpq.archive_add(gpu_ctx, 2, files[14:]))
+    arc = b"garbage before the first block" + b"".join(parts)
+    got = zpq.archive_extract(gpu_ctx, arc)
+    assert [(g["name"], g["comment"], g["data"]) for g in got] == files
+    assert all(g["sha1_ok"] and g["status"] == 0 for g in got)
+
+
+@pytest.mark.gpu
+def test_extract_reports_a_damaged_payload(zpq, gpu_ctx):
+    files = [("a", "5000 bytes", INPUTS["lcg4k"] + bytes(904)), ("b", "12 bytes", b"Hello World!")]
+    arc = bytearray(zpq.archive_add(gpu_ctx, 2, files))
+    arc[200] ^= 0x40                                       # inside a's coded payload
+    got = zpq.archive_extract(gpu_ctx, bytes(arc))
+    by_name = {g["name"]: g for g in got}
+    assert by_name["b"]["data"] == b"Hello World!" and by_name["b"]["sha1_ok"]
+    assert "a" not in by_name or not by_name["a"]["sha1_ok"] or by_name["a"]["data"] != files[0][2] or by_name["a"]["status"] != 0
+
+
+@pytest.mark.gpu
+def test_wrong_size_comment_only_costs_a_retry(zpq, gpu_ctx):
+    files = [("big", "3 bytes", INPUTS["text2k"] * 8), ("nohint", "", INPUTS["lcg4k"])]
+    arc = zpq.archive_add(gpu_ctx, 1, files)
+    got = zpq.archive_extract(gpu_ctx, arc)
+    assert [(g["name"], g["data"]) for g in got] == [(nm, d) for nm, _, d in files]
+
+
+@pytest.mark.gpu
+def test_cli_level2_directory_round_trip_and_archive_bytes(tmp_path):
+    files = file_set(seed=5, n=300)
+    src = tmp_path / "in"
+    src.mkdir()
+    for nm, _, d in files:
+        (src / nm).write_bytes(d)
+    arc = str(tmp_path / "arc.zpaq")
+    r = subprocess.run([CLI, "a", arc, str(src), "-m2"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files added: %d" % len(files) in r.stdout, r.stderr
+    by_name = {nm: (nm, cm, d) for nm, cm, d in files}
+    listed = subprocess.run([CLI, "l", arc], capture_output=True, text=True).stdout.splitlines()
+    order = [ln.split(" (")[0] for ln in listed[2:-2]]
+    assert sorted(order) == sorted(by_name)
+    assert open(arc, "rb").read() == oracle_archive(2, [by_name[nm] for nm in order])
+    out = tmp_path / "out"
+    r = subprocess.run([CLI, "x", arc, "-to", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files extracted: %d" % len(files) in r.stdout, r.stderr
+    for nm, _, d in files:
+        assert (out / nm).read_bytes() == d

@@ -9,4 +9,4 @@ from .binding import (  # noqa: F401
     FLAG_GENERIC, FLAG_LANES, FLAG_PP, Block, Context, Model, ZpqError, level_header, lib, lib_path,
     scan_header, status_string,
 )
-from .frontend import Compressor, Decompresser  # noqa: F401,E402
+from .frontend import Compressor, Decompresser, archive_add, archive_extract  # noqa: F401,E402

@@ -61,6 +61,10 @@ def lib():
     L.zpq_encode_blocks_dev.argtypes = enc
     L.zpq_decode_blocks.argtypes = dec
     L.zpq_decode_blocks_dev.argtypes = dec
+    L.zpq_sha1_blocks.argtypes = [vp, i32, vp, vp, vp]
+    L.zpq_sha1_blocks_dev.argtypes = [vp, i32, vp, vp, vp]
+    L.zpq_sha1_ranges_dev.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.zpq_ctx_device.argtypes = [vp]
     L.zpq_block_create.argtypes = [vp, vp, vp]
     L.zpq_block_destroy.argtypes = [vp]
     L.zpq_block_encode_segment.argtypes = [vp, u8p, C.c_size_t, u32, vp, C.c_size_t, vp]
@@ -188,6 +192,18 @@ class Context:
             o = int(out_off[i])
             res.append(out[o:o + min(int(out_len[i]), caps[i])].tobytes())
         return res, status, out_len
+
+    def sha1_blocks(self, blocks):
+        """SHA-1 of each byte string, one message per GPU lane (zpq_sha1_blocks; sha1.v:6-146)."""
+        nb = len(blocks)
+        in_off = _offsets([len(b) for b in blocks])
+        src = np.frombuffer(b"".join(blocks) + b"\0", dtype=np.uint8)
+        out = np.zeros(20 * nb + 1, dtype=np.uint8)
+        _ck(lib().zpq_sha1_blocks(self.h, nb, src.ctypes.data, in_off.ctypes.data, out.ctypes.data), "zpq_sha1_blocks")
+        return [out[20 * i:20 * i + 20].tobytes() for i in range(nb)]
+
+    def sha1_blocks_dev(self, nblocks, d_in, d_in_off, d_out20):
+        _ck(lib().zpq_sha1_blocks_dev(self.h, nblocks, d_in, d_in_off, d_out20), "zpq_sha1_blocks_dev")
 
     def decode_blocks(self, model, coded, cap, flags=FLAG_PP):
         nb = len(coded)

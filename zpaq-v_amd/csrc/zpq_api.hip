@@ -35,6 +35,7 @@ extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
                                 hipStream_t stream);
 extern "C" const char *zpq_chain_kernel_name(const DModel *M, int decode);
+extern "C" int zpq_launch_sha1(const uint8_t *in, const uint64_t *beg, const uint64_t *end, int n, uint8_t *out20, hipStream_t stream);
 
 #define HIPCK(x)                                                              \
     do {                                                                      \
@@ -161,6 +162,7 @@ extern "C" int zpq_ctx_sync(zpq_ctx *c)
     HIPCK(hipStreamSynchronize(c->stream));
     return ZPQ_OK;
 }
+extern "C" int zpq_ctx_device(const zpq_ctx *c) { return c ? c->device : -1; }
 extern "C" void *zpq_ctx_stream(zpq_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes)
 {
@@ -397,6 +399,51 @@ extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, co
 {
     return host_batch(c, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed,
                       final_code, first_byte, status, nullptr, nullptr, 0, nullptr, 0);
+}
+
+// ------------------------------------------------------------------ SHA-1 side kernel (sha1.v:6-146)
+extern "C" int zpq_sha1_blocks_dev(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20)
+{
+    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (nblocks == 0) return ZPQ_OK;
+    if (!in_off || !out20) return ZPQ_E_ARG;
+    HIPCK(hipSetDevice(c->device));
+    return zpq_launch_sha1(in, in_off, in_off + 1, nblocks, out20, c->stream);
+}
+
+extern "C" int zpq_sha1_ranges_dev(zpq_ctx *c, int nranges, const uint8_t *in, const uint64_t *begin, const uint64_t *end, uint8_t *out20)
+{
+    if (!c || nranges < 0) return ZPQ_E_ARG;
+    if (nranges == 0) return ZPQ_OK;
+    if (!begin || !end || !out20) return ZPQ_E_ARG;
+    HIPCK(hipSetDevice(c->device));
+    return zpq_launch_sha1(in, begin, end, nranges, out20, c->stream);
+}
+
+extern "C" int zpq_sha1_blocks(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20)
+{
+    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (nblocks == 0) return ZPQ_OK;
+    if (!in_off || !out20) return ZPQ_E_ARG;
+    for (int b = 0; b < nblocks; b++) if (in_off[b + 1] < in_off[b]) return ZPQ_E_ARG;
+    const size_t base = (size_t)in_off[0], in_bytes = (size_t)in_off[nblocks] - base;
+    if (in_bytes && !in) return ZPQ_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCK(hipSetDevice(c->device));
+    int rc;
+    const size_t offb = (size_t)(nblocks + 1) * 8;
+    if ((rc = c->s_in.ensure(in_bytes + 16)) || (rc = c->s_inoff.ensure(offb)) || (rc = c->s_out.ensure((size_t)nblocks * 20)))
+        return rc;
+    std::vector<uint64_t> rel((size_t)nblocks + 1);
+    for (int b = 0; b <= nblocks; b++) rel[b] = in_off[b] - base;
+    hipStream_t s = c->stream;
+    if (in_bytes) HIPCK(hipMemcpyAsync(c->s_in.p, in + base, in_bytes, hipMemcpyHostToDevice, s));
+    HIPCK(hipMemcpyAsync(c->s_inoff.p, rel.data(), offb, hipMemcpyHostToDevice, s));
+    rc = zpq_launch_sha1((const uint8_t *)c->s_in.p, (const uint64_t *)c->s_inoff.p, (const uint64_t *)c->s_inoff.p + 1, nblocks, (uint8_t *)c->s_out.p, s);
+    if (rc != ZPQ_OK) return rc;
+    HIPCK(hipMemcpyAsync(out20, c->s_out.p, (size_t)nblocks * 20, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    return ZPQ_OK;
 }
 
 // ------------------------------------------------------------------ one block, many segments

@@ -1,0 +1,434 @@
+// zpq_archive.cpp -- batch form of the reference CLI's add / extract / list loops
+// (cmd/main.v:239-470) on top of the C ABI.
+//
+// The reference CLI writes one block with one segment per file and runs a fresh Compressor
+// state machine per block (cmd/main.v:283-311); extraction walks find_block / find_filename /
+// decompress / read_segment_end block after block (cmd/main.v:342-380).  Blocks are independent
+// coding problems, so here a set of files is ONE GPU batch:
+//   add:     upload all files once -> zpq_encode_blocks_dev + zpq_sha1_blocks_dev on the same
+//            device buffer -> download coded payloads + digests -> host writes the framing.
+//            Byte-identical to the per-file Compressor loop.
+//   extract: host finds every block by the reference's rolling-hash locator
+//            (decompressor.v:227-241) and reads headers + first segment names; all modelled
+//            blocks with the same header are decoded by one zpq_decode_blocks_dev call, digests
+//            by one zpq_sha1_blocks_dev call; the host then walks each trailer the way
+//            Decoder.skip / read_segment_end do.  A block that turns out to hold more than one
+//            segment, a store-mode block, or anything unusual is replayed through the sequential
+//            Decompresser (state must persist across its segments).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+#include "../../include/zpaq_frontend.hpp"
+
+namespace zpaq {
+
+namespace {
+
+struct DevMem {
+    void *p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess ? ZPQ_OK : ZPQ_E_NOMEM; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+#define HK(x) do { if ((x) != hipSuccess) return ZPQ_E_NODEVICE; } while (0)
+
+// One message per GPU lane hashes ~18 MB/s, a host core ~400 MB/s: the side kernel wins once
+// the batch holds a few dozen messages' worth of its longest one.
+bool gpu_sha1_pays(uint64_t total, uint64_t longest) { return longest > 0 && total >= 24 * longest; }
+
+void host_sha1(const uint8_t *p, size_t n, uint8_t out[20])
+{
+    SHA1 s;
+    s.write_bytes(p, n);
+    const std::vector<uint8_t> h = s.result();
+    memcpy(out, h.data(), 20);
+}
+
+struct VecWriter : Writer {
+    std::vector<uint8_t> *v;
+    explicit VecWriter(std::vector<uint8_t> *vv) : v(vv) {}
+    void put(int c) override { v->push_back((uint8_t)c); }
+    void write(const uint8_t *buf, int n) override { v->insert(v->end(), buf, buf + n); }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ add
+int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive)
+{
+    if (!archive || level < 0 || level > 5) return ZPQ_E_ARG;
+    VecWriter w(archive);
+    const int n = (int)files.size();
+    if (n == 0) return ZPQ_OK;
+    if (level == 0) {                                   // store mode has no coder: host only (compressor.v:297-354)
+        for (const ArchiveFile &f : files) {
+            Compressor c(nullptr);
+            FileReader r(f.data);
+            c.set_output(&w);
+            c.start_block(0);
+            c.start_segment(f.name, f.comment);
+            c.set_input(&r);
+            while (c.compress(65536)) {}
+            c.end_segment();
+            c.end_block();
+        }
+        return ZPQ_OK;
+    }
+    if (!ctx) return ZPQ_E_NODEVICE;
+    uint8_t hdr[256];
+    int hlen = 0, cend = 0, hbegin = 0, hend = 0;
+    int rc = zpq_level_header(level, hdr, (int)sizeof hdr, &hlen, &cend, &hbegin, &hend);
+    if (rc != ZPQ_OK) return rc;
+    zpq_model *model = nullptr;
+    if ((rc = zpq_model_create(hdr, hlen, cend, hbegin, hend, &model)) != ZPQ_OK) return rc;
+    struct ModelGuard { zpq_model *m; ~ModelGuard() { zpq_model_destroy(m); } } guard{model};
+
+    std::vector<uint64_t> in_off((size_t)n + 1, 0), out_off((size_t)n + 1, 0);
+    uint64_t longest = 0;
+    for (int i = 0; i < n; i++) {
+        const uint64_t len = files[i].data.size();
+        if (len > 0xFFFFFF00ull) return ZPQ_E_TOOBIG;
+        in_off[i + 1] = in_off[i] + len;
+        out_off[i + 1] = out_off[i] + len + len / 4 + 1024;      // overflowing blocks are redone below
+        longest = std::max(longest, len);
+    }
+    const uint64_t total = in_off[n], out_total = out_off[n];
+    const bool gpu_sha = gpu_sha1_pays(total, longest);
+
+    HK(hipSetDevice(zpq_ctx_device(ctx)));
+    hipStream_t s = (hipStream_t)zpq_ctx_stream(ctx);
+    DevMem d_in, d_inoff, d_out, d_outoff, d_len, d_st, d_sha;
+    if ((rc = d_in.alloc(total + 64)) || (rc = d_inoff.alloc(((size_t)n + 1) * 8)) || (rc = d_out.alloc(out_total + 64)) ||
+        (rc = d_outoff.alloc(((size_t)n + 1) * 8)) || (rc = d_len.alloc((size_t)n * 4)) || (rc = d_st.alloc((size_t)n * 4)) ||
+        (rc = d_sha.alloc((size_t)n * 20)))
+        return rc;
+    for (int i = 0; i < n; i++)
+        if (!files[i].data.empty())
+            HK(hipMemcpyAsync(d_in.as<uint8_t>() + in_off[i], files[i].data.data(), files[i].data.size(), hipMemcpyHostToDevice, s));
+    HK(hipMemcpyAsync(d_inoff.p, in_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+    HK(hipMemcpyAsync(d_outoff.p, out_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+    HK(hipMemsetAsync(d_st.p, 0xff, (size_t)n * 4, s));
+    // compress() is always entered by the CLI loop, so the PP byte is coded first (compressor.v:271-274)
+    if ((rc = zpq_encode_blocks_dev(ctx, model, n, d_in.as<uint8_t>(), d_inoff.as<uint64_t>(), ZPQ_FLAG_PP, d_out.as<uint8_t>(),
+                                    d_outoff.as<uint64_t>(), d_len.as<uint32_t>(), d_st.as<int32_t>())) != ZPQ_OK)
+        return rc;
+    if (gpu_sha && (rc = zpq_sha1_blocks_dev(ctx, n, d_in.as<uint8_t>(), d_inoff.as<uint64_t>(), d_sha.as<uint8_t>())) != ZPQ_OK)
+        return rc;
+    std::vector<uint32_t> lens((size_t)n);
+    std::vector<int32_t> st((size_t)n);
+    std::vector<uint8_t> sha((size_t)n * 20), coded((size_t)out_total);
+    HK(hipMemcpyAsync(lens.data(), d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HK(hipMemcpyAsync(st.data(), d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (gpu_sha) HK(hipMemcpyAsync(sha.data(), d_sha.p, (size_t)n * 20, hipMemcpyDeviceToHost, s));
+    HK(hipMemcpyAsync(coded.data(), d_out.p, (size_t)out_total, hipMemcpyDeviceToHost, s));
+    HK(hipStreamSynchronize(s));
+    if (!gpu_sha) for (int i = 0; i < n; i++) host_sha1(files[i].data.data(), files[i].data.size(), &sha[(size_t)i * 20]);
+
+    // a payload that outgrew its slab (possible: worst case ~16x) is coded again alone
+    std::map<int, std::vector<uint8_t>> redo;
+    for (int i = 0; i < n; i++) {
+        if (st[i] == ZPQ_OK) continue;
+        if (st[i] != ZPQ_E_OVERFLOW) return st[i];
+        std::vector<uint8_t> big(files[i].data.size() * 17 + 4096);
+        const uint64_t io[2] = {0, files[i].data.size()}, oo[2] = {0, big.size()};
+        uint32_t bl = 0;
+        int32_t bs = 0;
+        if ((rc = zpq_encode_blocks(ctx, model, 1, files[i].data.data(), io, ZPQ_FLAG_PP, big.data(), oo, &bl, &bs)) != ZPQ_OK) return rc;
+        if (bs != ZPQ_OK) return bs;
+        big.resize(bl);
+        redo[i] = std::move(big);
+    }
+    for (int i = 0; i < n; i++) {
+        framing::block_header(w, hdr, hlen, cend, hbegin, hend);
+        framing::segment_header(w, files[i].name, files[i].comment);
+        auto it = redo.find(i);
+        if (it != redo.end()) w.write(it->second.data(), (int)it->second.size());
+        else w.write(coded.data() + out_off[i], (int)lens[i]);
+        framing::segment_trailer(w, &sha[(size_t)i * 20]);
+        framing::block_end(w);
+    }
+    return ZPQ_OK;
+}
+
+// ------------------------------------------------------------------ extract / list
+namespace {
+
+const int kCompSize[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};
+
+struct BlockRec {
+    size_t tag_pos = 0;          // where a Decompresser must start reading to find this block again
+    std::vector<uint8_t> hdr;
+    int cend = 0, hbegin = 0, hend = 0, ncomp = 0;
+    bool has_segment = false;
+    std::string name, comment;
+    size_t payload = 0;          // first byte of the coded data of the first segment
+    size_t next_tag = 0;         // start of the next block's locator window (or archive end)
+};
+
+// find_block (decompressor.v:219-346) on a flat buffer: false = the reference's loop would stop here
+bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b)
+{
+    uint32_t h1 = 0x3D49B113u, h2 = 0x29EB7F93u, h3 = 0x2614BE13u, h4 = 0x3828EB13u;   // decompressor.v:227-236
+    for (;;) {
+        if (pos >= n) return false;
+        const uint32_t c = a[pos++];
+        h1 = h1 * 12 + c; h2 = h2 * 20 + c; h3 = h3 * 28 + c; h4 = h4 * 44 + c;
+        if (h1 == 0xB16B88F1u && h2 == 0xFF5376F1u && h3 == 0x72AC5BF1u && h4 == 0x2F909AF1u) break;
+    }
+    b.tag_pos = pos >= 16 ? pos - 16 : 0;              // the four hashes forget everything older than 16 bytes
+    auto get = [&]() -> int { return pos < n ? a[pos++] : -1; };
+    const int level = get();
+    if (level != 1 && level != 2) return false;
+    if (get() != 1) return false;
+    const int lo = get(), hi = get();
+    if (lo < 0 || hi < 0) return false;
+    const int hsize = lo + hi * 256;
+    b.hdr.clear();
+    for (int i = 0; i < 5; i++) { const int v = get(); if (v < 0) return false; b.hdr.push_back((uint8_t)v); }
+    b.ncomp = b.hdr[4];
+    for (int i = 0; i < b.ncomp; i++) {
+        const int t = get();
+        if (t < 0 || t >= 10) return false;
+        b.hdr.push_back((uint8_t)t);
+        for (int j = 1; j < kCompSize[t]; j++) { const int v = get(); if (v < 0) return false; b.hdr.push_back((uint8_t)v); }
+    }
+    if (get() != 0) return false;
+    b.hdr.push_back(0);
+    b.cend = (int)b.hdr.size() - 1;
+    b.hbegin = (int)b.hdr.size();
+    const int hcomp_len = hsize - (int)b.hdr.size();
+    for (int i = 0; i < hcomp_len; i++) { const int v = get(); if (v < 0) return false; b.hdr.push_back((uint8_t)v); }
+    b.hend = (int)b.hdr.size() - 1;
+    // find_filename (decompressor.v:350-429) for the first segment
+    b.has_segment = false;
+    b.name.clear(); b.comment.clear();
+    size_t q = pos;
+    auto get2 = [&]() -> int { return q < n ? a[q++] : -1; };
+    const int marker = get2();
+    if (marker < 0 || marker == 0xFF) { pos = q; return true; }
+    for (;;) { const int c = get2(); if (c < 0) return true; if (c == 0) break; if (c == 0xFF) { pos = q; return true; } b.name.push_back((char)c); }
+    for (;;) { const int c = get2(); if (c < 0) return true; if (c == 0) break; b.comment.push_back((char)c); }
+    if (get2() < 0) return true;
+    b.has_segment = true;
+    b.payload = q;
+    pos = q;
+    return true;
+}
+
+// every segment of one block through the sequential front end
+void replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool want_data, std::vector<ArchiveFile> *out)
+{
+    FileReader r(std::vector<uint8_t>(a + from, a + to));
+    Decompresser d(ctx);
+    d.set_input(&r);
+    if (!d.find_block()) {
+        if (d.last_error() != ZPQ_OK) { ArchiveFile f; f.status = d.last_error(); out->push_back(std::move(f)); }
+        return;
+    }
+    while (d.find_filename()) {
+        ArchiveFile f;
+        f.name = d.get_filename();
+        f.comment = d.get_comment();
+        FileWriter fw;
+        d.set_output(&fw);
+        while (d.decompress(65536)) {}
+        f.status = d.last_error();
+        const std::vector<uint8_t> digest = d.get_sha1();
+        d.read_segment_end();
+        uint8_t stored[20];
+        if (d.stored_sha1(stored)) f.sha1_ok = memcmp(stored, digest.data(), 20) == 0;
+        f.size = fw.bytes().size();
+        if (want_data) f.data = fw.bytes();
+        const int fst = f.status;
+        out->push_back(std::move(f));
+        if (fst != ZPQ_OK) break;
+    }
+}
+
+uint64_t size_hint(const std::string &comment)            // the CLI's "<n> bytes" comment (cmd/main.v:300-302); only a capacity hint
+{
+    uint64_t v = 0;
+    size_t i = 0;
+    while (i < comment.size() && comment[i] >= '0' && comment[i] <= '9' && v < (1ull << 40)) v = v * 10 + (uint64_t)(comment[i++] - '0');
+    return (i > 0 && comment.compare(i, std::string::npos, " bytes") == 0) ? v : ~0ull;
+}
+
+}  // namespace
+
+int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
+{
+    if (!files || (n && !arc)) return ZPQ_E_ARG;
+    // ---- pass 1: every block the sequential loop would visit
+    std::vector<BlockRec> blocks;
+    {
+        size_t pos = 0;
+        for (;;) {
+            BlockRec b;
+            if (!next_block(arc, n, pos, b)) break;
+            blocks.push_back(std::move(b));
+        }
+        for (size_t i = 0; i < blocks.size(); i++) blocks[i].next_tag = i + 1 < blocks.size() ? blocks[i + 1].tag_pos : n;
+    }
+    // ---- pass 2: one batch per distinct header over the single-segment candidates
+    struct Decoded { bool done = false; ArchiveFile f; };
+    std::vector<Decoded> dec(blocks.size());
+    std::map<std::vector<uint8_t>, std::vector<int>> groups;
+    for (size_t i = 0; i < blocks.size(); i++)
+        if (blocks[i].ncomp > 0 && blocks[i].has_segment && ctx && n < 0xFFFFFF00ull) groups[blocks[i].hdr].push_back((int)i);
+    if (!groups.empty()) {
+        HK(hipSetDevice(zpq_ctx_device(ctx)));
+        hipStream_t s = (hipStream_t)zpq_ctx_stream(ctx);
+        DevMem d_arc;
+        int rc;
+        if ((rc = d_arc.alloc(n + 64))) return rc;
+        HK(hipMemcpyAsync(d_arc.p, arc, n, hipMemcpyHostToDevice, s));
+        for (auto &g : groups) {
+            const BlockRec &b0 = blocks[(size_t)g.second[0]];
+            zpq_model *model = nullptr;
+            if (zpq_model_create(b0.hdr.data(), (int)b0.hdr.size(), b0.cend, b0.hbegin, b0.hend, &model) != ZPQ_OK) continue;   // replayed below
+            struct ModelGuard { zpq_model *m; ~ModelGuard() { zpq_model_destroy(m); } } guard{model};
+            std::vector<int> todo = g.second;
+            std::vector<uint64_t> capmul(blocks.size(), 1);
+            for (int attempt = 0; attempt < 4 && !todo.empty(); attempt++) {
+                const int m = (int)todo.size();
+                // input ranges: the decoder stops at the EOF symbol, so a range may run on to the next
+                // candidate's payload (in_off must be contiguous); bytes after the payload are never coded
+                std::vector<uint64_t> in_off((size_t)m + 1), out_off((size_t)m + 1, 0);
+                for (int k = 0; k < m; k++) in_off[k] = blocks[(size_t)todo[k]].payload;
+                in_off[m] = n;
+                for (int k = 0; k < m; k++) {
+                    const BlockRec &b = blocks[(size_t)todo[k]];
+                    const uint64_t hint = size_hint(b.comment);
+                    const uint64_t paylen = b.next_tag - b.payload;
+                    uint64_t cap = (hint != ~0ull && attempt == 0) ? hint + 64 : paylen * 8 + 65536;
+                    cap *= capmul[(size_t)todo[k]];
+                    cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
+                    out_off[k + 1] = out_off[k] + ((cap + 15) & ~15ull);
+                }
+                DevMem d_inoff, d_out, d_outoff, d_u32, d_st, d_sha;
+                const size_t u = (size_t)m * 4;
+                if ((rc = d_inoff.alloc(((size_t)m + 1) * 8)) || (rc = d_outoff.alloc(((size_t)m + 1) * 8)) || (rc = d_out.alloc(out_off[m] + 64)) ||
+                    (rc = d_u32.alloc(u * 4)) || (rc = d_st.alloc(u)) || (rc = d_sha.alloc((size_t)m * 20)))
+                    return rc;
+                HK(hipMemcpyAsync(d_inoff.p, in_off.data(), ((size_t)m + 1) * 8, hipMemcpyHostToDevice, s));
+                HK(hipMemcpyAsync(d_outoff.p, out_off.data(), ((size_t)m + 1) * 8, hipMemcpyHostToDevice, s));
+                HK(hipMemsetAsync(d_st.p, 0xff, u, s));
+                uint32_t *d_len = d_u32.as<uint32_t>(), *d_cons = d_len + m, *d_code = d_cons + m, *d_first = d_code + m;
+                if ((rc = zpq_decode_blocks_dev(ctx, model, m, d_arc.as<uint8_t>(), d_inoff.as<uint64_t>(), ZPQ_FLAG_PP, d_out.as<uint8_t>(),
+                                                d_outoff.as<uint64_t>(), d_len, d_cons, d_code, d_first, d_st.as<int32_t>())) != ZPQ_OK)
+                    return rc;
+                std::vector<uint32_t> meta((size_t)m * 4);
+                std::vector<int32_t> st((size_t)m);
+                HK(hipMemcpyAsync(meta.data(), d_u32.p, u * 4, hipMemcpyDeviceToHost, s));
+                HK(hipMemcpyAsync(st.data(), d_st.p, u, hipMemcpyDeviceToHost, s));
+                HK(hipStreamSynchronize(s));
+                const uint32_t *len = meta.data(), *cons = len + m, *code = cons + m, *first = code + m;
+                // digests of the decoded bytes (capacity-strided slabs: explicit ranges)
+                uint64_t tot = 0, longest = 0;
+                for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) { tot += len[k]; longest = std::max<uint64_t>(longest, len[k]); }
+                const bool gpu_sha = gpu_sha1_pays(tot, longest);
+                std::vector<uint8_t> sha((size_t)m * 20, 0), slab;
+                if (gpu_sha) {
+                    std::vector<uint64_t> rng((size_t)m * 2);      // begin[0..m) then end[0..m)
+                    for (int k = 0; k < m; k++) { rng[(size_t)k] = out_off[k]; rng[(size_t)m + k] = out_off[k] + (st[k] == ZPQ_OK ? len[k] : 0); }
+                    DevMem d_rng;
+                    if ((rc = d_rng.alloc((size_t)m * 16))) return rc;
+                    HK(hipMemcpyAsync(d_rng.p, rng.data(), (size_t)m * 16, hipMemcpyHostToDevice, s));
+                    if ((rc = zpq_sha1_ranges_dev(ctx, m, d_out.as<uint8_t>(), d_rng.as<uint64_t>(), d_rng.as<uint64_t>() + m, d_sha.as<uint8_t>())) != ZPQ_OK)
+                        return rc;
+                    HK(hipMemcpyAsync(sha.data(), d_sha.p, (size_t)m * 20, hipMemcpyDeviceToHost, s));
+                    HK(hipStreamSynchronize(s));
+                }
+                if (want_data || !gpu_sha) {
+                    slab.resize((size_t)out_off[m]);
+                    HK(hipMemcpyAsync(slab.data(), d_out.p, slab.size(), hipMemcpyDeviceToHost, s));
+                    HK(hipStreamSynchronize(s));
+                    if (!gpu_sha) for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) host_sha1(slab.data() + out_off[k], len[k], &sha[(size_t)k * 20]);
+                }
+                // ---- pass 3: trailer walk per block (Decoder.skip decoder.v:151-196, read_segment_end decompressor.v:590-635)
+                std::vector<int> again;
+                for (int k = 0; k < m; k++) {
+                    const size_t bi = (size_t)todo[k];
+                    const BlockRec &b = blocks[bi];
+                    if (st[k] == ZPQ_E_OVERFLOW) { capmul[bi] *= 8; again.push_back(todo[k]); continue; }
+                    if (st[k] != ZPQ_OK || first[k] == 1u) continue;               // replayed (reports the error there)
+                    size_t p = b.payload + cons[k];
+                    auto get = [&]() -> int { return p < n ? arc[p++] : -1; };
+                    uint32_t curr = code[k];
+                    bool ok = true;
+                    int marker = -1;
+                    if (curr == 0) { const int c = get(); if (c < 0) ok = false; else curr = (uint32_t)c; }
+                    while (ok && curr != 0) { const int c = get(); if (c < 0) { ok = false; break; } curr = (curr << 8) | (uint32_t)c; }
+                    while (ok) { const int c = get(); if (c < 0) break; if (c != 0) { marker = c; break; } }
+                    bool sha_ok = true;
+                    if (marker == 253) {
+                        if (p + 20 > n) continue;
+                        sha_ok = memcmp(arc + p, &sha[(size_t)k * 20], 20) == 0;
+                        p += 20;
+                    }
+                    if (get() != 0xFF) continue;                                   // more segments (or damage): replay sequentially
+                    Decoded &d = dec[bi];
+                    d.done = true;
+                    d.f.name = b.name;
+                    d.f.comment = b.comment;
+                    d.f.sha1_ok = sha_ok;
+                    d.f.size = first[k] == 0xFFFFFFFFu ? 0 : len[k];
+                    if (want_data && d.f.size) d.f.data.assign(slab.begin() + (ptrdiff_t)out_off[k], slab.begin() + (ptrdiff_t)(out_off[k] + len[k]));
+                }
+                todo.swap(again);
+            }
+        }
+    }
+    // ---- everything else, in archive order
+    for (size_t i = 0; i < blocks.size(); i++) {
+        if (dec[i].done) { files->push_back(std::move(dec[i].f)); continue; }
+        replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
+    }
+    return ZPQ_OK;
+}
+
+}  // namespace zpaq
+
+// ------------------------------------------------------------------ flat C surface for ctypes
+struct zpqf_archive {
+    std::vector<uint8_t> bytes;
+    std::vector<zpaq::ArchiveFile> files;
+};
+
+extern "C" {
+zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
+                               const uint8_t *const *data, const uint64_t *lens, int *rc)
+{
+    zpqf_archive *h = new zpqf_archive();
+    std::vector<zpaq::ArchiveFile> files((size_t)(nfiles > 0 ? nfiles : 0));
+    for (int i = 0; i < nfiles; i++) {
+        files[(size_t)i].name = names[i];
+        files[(size_t)i].comment = comments[i];
+        files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
+    }
+    const int r = zpaq::archive_add(ctx, level, files, &h->bytes);
+    if (rc) *rc = r;
+    return h;
+}
+size_t zpqf_archive_bytes(zpqf_archive *h, const uint8_t **p) { *p = h->bytes.data(); return h->bytes.size(); }
+zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data, int *rc)
+{
+    zpqf_archive *h = new zpqf_archive();
+    const int r = zpaq::archive_extract(ctx, arc, n, want_data != 0, &h->files);
+    if (rc) *rc = r;
+    return h;
+}
+int zpqf_archive_nfiles(zpqf_archive *h) { return (int)h->files.size(); }
+const char *zpqf_archive_name(zpqf_archive *h, int i) { return h->files[(size_t)i].name.c_str(); }
+const char *zpqf_archive_comment(zpqf_archive *h, int i) { return h->files[(size_t)i].comment.c_str(); }
+uint64_t zpqf_archive_size(zpqf_archive *h, int i) { return h->files[(size_t)i].size; }
+int zpqf_archive_sha1_ok(zpqf_archive *h, int i) { return h->files[(size_t)i].sha1_ok ? 1 : 0; }
+int zpqf_archive_status(zpqf_archive *h, int i) { return h->files[(size_t)i].status; }
+const uint8_t *zpqf_archive_data(zpqf_archive *h, int i) { return h->files[(size_t)i].data.data(); }
+void zpqf_archive_free(zpqf_archive *h) { delete h; }
+}

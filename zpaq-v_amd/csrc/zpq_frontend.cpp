@@ -91,6 +91,37 @@ std::vector<uint8_t> SHA1::result()
 // ------------------------------------------------------------------ Compressor
 static const uint8_t kLocator[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
 
+namespace framing {
+void block_header(Writer &w, const uint8_t *hdr, int len, int cend, int hbegin, int hend)
+{
+    for (uint8_t b : kLocator) w.put(b);                            // compressor.v:63-75
+    w.put(0x7a); w.put(0x50); w.put(0x51);
+    w.put((len >= 5 && hdr[4] != 0) ? 1 : 2);                       // :157-158
+    w.put(1);
+    const int hsize = (cend + 1) + (hend - hbegin + 1);             // :167
+    w.put(hsize & 0xFF);
+    w.put((hsize >> 8) & 0xFF);
+    for (int i = 0; i <= cend && i < len; i++) w.put(hdr[i]);
+    for (int i = hbegin; i <= hend && i < len; i++) w.put(hdr[i]);
+}
+void segment_header(Writer &w, const std::string &filename, const std::string &comment)
+{
+    w.put(1);                                                       // compressor.v:217-235
+    for (unsigned char c : filename) w.put(c);
+    w.put(0);
+    for (unsigned char c : comment) w.put(c);
+    w.put(0);
+    w.put(0);
+}
+void segment_trailer(Writer &w, const uint8_t sha1[20])
+{
+    for (int i = 0; i < 4; i++) w.put(0);                           // compressor.v:382-385
+    w.put(253);                                                     // :389-395
+    for (int i = 0; i < 20; i++) w.put(sha1[i]);
+}
+void block_end(Writer &w) { w.put(0xFF); }                          // compressor.v:407-410
+}  // namespace framing
+
 Compressor::Compressor(zpq_ctx *ctx)
     : state_(kStart), ctx_(ctx), model_(nullptr), block_(nullptr), input_(nullptr), output_(nullptr),
       level_(1), ncomp_(0), pp_coded_(false), first_byte_(true), err_(ZPQ_OK)
@@ -113,17 +144,7 @@ void Compressor::start_block(int level)
     zpq_level_header(level, hdr, (int)sizeof hdr, &len, &cend, &hbegin, &hend);   // levels.v + compressor.v:96-145
     header_.assign(hdr, hdr + len);
     ncomp_ = len >= 5 ? hdr[4] : 0;
-    if (output_) {
-        for (uint8_t b : kLocator) output_->put(b);                 // compressor.v:63-75
-        output_->put(0x7a); output_->put(0x50); output_->put(0x51);
-        output_->put((len >= 5 && hdr[4] != 0) ? 1 : 2);            // :157-158
-        output_->put(1);
-        const int hsize = (cend + 1) + (hend - hbegin + 1);         // :167
-        output_->put(hsize & 0xFF);
-        output_->put((hsize >> 8) & 0xFF);
-        for (int i = 0; i <= cend && i < len; i++) output_->put(hdr[i]);
-        for (int i = hbegin; i <= hend && i < len; i++) output_->put(hdr[i]);
-    }
+    if (output_) framing::block_header(*output_, hdr, len, cend, hbegin, hend);
     drop_block();
     err_ = zpq_model_create(hdr, len, cend, hbegin, hend, &model_); // Predictor.init(&z) (:184-185)
     if (err_ == ZPQ_OK && ncomp_ > 0 && ctx_) err_ = zpq_block_create(ctx_, model_, &block_);
@@ -148,14 +169,7 @@ void Compressor::start_block_hcomp(const std::string &hcomp)
 void Compressor::start_segment(const std::string &filename, const std::string &comment)
 {
     if (state_ != kBlock) return;
-    if (output_) {                                                  // compressor.v:217-235
-        output_->put(1);
-        for (unsigned char c : filename) output_->put(c);
-        output_->put(0);
-        for (unsigned char c : comment) output_->put(c);
-        output_->put(0);
-        output_->put(0);
-    }
+    if (output_) framing::segment_header(*output_, filename, comment);
     sha1_.init();
     stage_.clear();
     pp_coded_ = false;
@@ -222,11 +236,10 @@ void Compressor::end_segment()
                 err_ = zpq_block_encode_segment(block_, stage_.data(), stage_.size(), flags, out.data(), out.size(), &n);
                 if (err_ == ZPQ_OK) output_->write(out.data(), (int)n);
             } else if (err_ == ZPQ_OK) err_ = ZPQ_E_NODEVICE;
-            for (int i = 0; i < 4; i++) output_->put(0);            // :382-385
         }
-        const std::vector<uint8_t> h = sha1_.result();             // :389-395
-        output_->put(253);
-        for (uint8_t b : h) output_->put(b);
+        const std::vector<uint8_t> h = sha1_.result();
+        if (level_ == 0) { output_->put(253); for (uint8_t b : h) output_->put(b); }
+        else framing::segment_trailer(*output_, h.data());
     }
     stage_.clear();
     state_ = kBlock;
@@ -235,7 +248,7 @@ void Compressor::end_segment()
 void Compressor::end_block()
 {
     if (state_ != kBlock) return;
-    if (output_) output_->put(0xFF);
+    if (output_) framing::block_end(*output_);
     state_ = kStart;
 }
 
@@ -243,7 +256,7 @@ void Compressor::end_block()
 Decompresser::Decompresser(zpq_ctx *ctx)
     : state_(kStart), ctx_(ctx), model_(nullptr), block_(nullptr), input_(nullptr), output_(nullptr),
       pos_(0), slurped_(false), ncomp_(0), store_count_(0), first_seg_(true), decoded_(false),
-      seg_pos_(0), seg_empty_(false), final_code_(0), segs_in_block_(0), err_(ZPQ_OK)
+      seg_pos_(0), seg_empty_(false), final_code_(0), segs_in_block_(0), err_(ZPQ_OK), has_stored_sha1_(false)
 {
 }
 Decompresser::~Decompresser() { drop_block(); }
@@ -448,8 +461,10 @@ void Decompresser::read_segment_end()
     } else {
         marker = get();
     }
+    has_stored_sha1_ = false;
     if (marker == 253) {                                 // stored SHA-1: read, compared, result unused (:608-628)
-        for (int i = 0; i < 20; i++) (void)get();
+        for (int i = 0; i < 20; i++) { const int c = get(); stored_sha1_[i] = (uint8_t)(c < 0 ? 0 : c); }
+        has_stored_sha1_ = true;
     }
     state_ = kBlock;
 }

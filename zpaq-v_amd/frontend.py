@@ -42,6 +42,23 @@ def _lib():
     L.zpqf_decompresser_output.restype = C.c_size_t
     L.zpqf_decompresser_output.argtypes = [vp, vp]
     L.zpqf_decompresser_sha1.argtypes = [vp, vp]
+    L.zpqf_archive_add.restype = vp
+    L.zpqf_archive_add.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.zpqf_archive_bytes.restype = C.c_size_t
+    L.zpqf_archive_bytes.argtypes = [vp, vp]
+    L.zpqf_archive_extract.restype = vp
+    L.zpqf_archive_extract.argtypes = [vp, u8p, C.c_size_t, C.c_int, vp]
+    L.zpqf_archive_nfiles.argtypes = [vp]
+    for fn in ("name", "comment"):
+        getattr(L, "zpqf_archive_" + fn).restype = C.c_char_p
+        getattr(L, "zpqf_archive_" + fn).argtypes = [vp, C.c_int]
+    L.zpqf_archive_size.restype = C.c_uint64
+    L.zpqf_archive_size.argtypes = [vp, C.c_int]
+    L.zpqf_archive_sha1_ok.argtypes = [vp, C.c_int]
+    L.zpqf_archive_status.argtypes = [vp, C.c_int]
+    L.zpqf_archive_data.restype = vp
+    L.zpqf_archive_data.argtypes = [vp, C.c_int]
+    L.zpqf_archive_free.argtypes = [vp]
     L._zpqf_ready = True
     return L
 
@@ -148,3 +165,47 @@ class Decompresser:
         out = C.create_string_buffer(20)
         self._L.zpqf_decompresser_sha1(self.h, out)
         return out.raw
+
+
+def archive_add(ctx, level, files):
+    """zpaq::archive_add: the reference CLI's add loop (cmd/main.v:283-311) for a list of
+    (name, comment, data) as ONE GPU batch.  Returns the archive bytes."""
+    L = _lib()
+    n = len(files)
+    names = (C.c_char_p * n)(*[f[0].encode() for f in files])
+    comments = (C.c_char_p * n)(*[f[1].encode() for f in files])
+    keep = [bytes(f[2]) for f in files]
+    data = (C.c_char_p * n)(*keep)
+    lens = (C.c_uint64 * n)(*[len(k) for k in keep])
+    rc = C.c_int(0)
+    h = L.zpqf_archive_add(ctx.h if ctx is not None else None, level, n, names, comments, data, lens, C.byref(rc))
+    try:
+        if rc.value != 0:
+            raise B.ZpqError(rc.value, "archive_add")
+        p = C.c_void_p()
+        k = L.zpqf_archive_bytes(h, C.byref(p))
+        return C.string_at(p, k) if k else b""
+    finally:
+        L.zpqf_archive_free(h)
+
+
+def archive_extract(ctx, archive, want_data=True):
+    """zpaq::archive_extract: every segment of every block in archive order
+    (cmd/main.v:342-380,440-465).  Returns dicts name/comment/size/sha1_ok/status/data."""
+    L = _lib()
+    archive = bytes(archive)
+    rc = C.c_int(0)
+    h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive), 1 if want_data else 0, C.byref(rc))
+    try:
+        if rc.value != 0:
+            raise B.ZpqError(rc.value, "archive_extract")
+        out = []
+        for i in range(L.zpqf_archive_nfiles(h)):
+            size = L.zpqf_archive_size(h, i)
+            d = C.string_at(L.zpqf_archive_data(h, i), size) if (want_data and size) else b""
+            out.append(dict(name=L.zpqf_archive_name(h, i).decode(errors="replace"),
+                            comment=L.zpqf_archive_comment(h, i).decode(errors="replace"), size=size,
+                            sha1_ok=bool(L.zpqf_archive_sha1_ok(h, i)), status=L.zpqf_archive_status(h, i), data=d))
+        return out
+    finally:
+        L.zpqf_archive_free(h)
