@@ -126,6 +126,14 @@ int zpq_decode_blocks_dev(zpq_ctx *, const zpq_model *, int nblocks, const uint8
                           uint32_t *final_code, uint32_t *first_byte, int32_t *status);
 
 /*
+ * Compaction of capacity-strided output slabs: dst[dst_off[b] ..] = src[src_off[b] .. + len[b]).
+ * Device pointers, enqueue only.  Lets a front end download exactly the coded bytes that
+ * Writer.put() would have received (encoder.v:76-83) instead of whole slabs.
+ */
+int zpq_gather_dev(zpq_ctx *, int nblocks, const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
+                   uint8_t *dst, const uint64_t *dst_off);
+
+/*
  * SHA-1 of nblocks independent byte ranges in[in_off[b] .. in_off[b+1]) -> out20[20*b ..]:
  * the digest Compressor/Decompresser accumulate with sha1.put() per uncompressed byte
  * (compressor.v:284, decompressor.v:493,505; sha1.v:6-146) and store behind marker 253 in the

@@ -136,6 +136,24 @@ def test_extract_mixed_archive_levels_store_and_multi_segment_blocks(zpq, gpu_ct
 
 
 @pytest.mark.gpu
+def test_block_found_without_the_locator_at_stream_start(zpq, gpu_ctx):
+    """find_block's initial hash state stands for the 13 locator bytes (decompressor.v:227-236): a stream that
+    starts with "zPQ" is a block; the same 3 bytes later in the stream are not."""
+    files = file_set(seed=2, n=2)
+    arc = zpq.archive_add(gpu_ctx, 2, files)
+    assert arc[13:16] == b"zPQ"
+    got = zpq.archive_extract(gpu_ctx, arc[13:])
+    assert [(g["name"], g["data"]) for g in got] == [(nm, d) for nm, _, d in files]
+    d = zpq.Decompresser(gpu_ctx)
+    d.set_input(arc[13:])
+    assert d.find_block()
+    assert zpq.archive_extract(gpu_ctx, b"x" + arc[13:])[0]["name"] == files[1][0]     # first block is no longer found
+    d = zpq.Decompresser(gpu_ctx)
+    d.set_input(b"x" + arc[13:])
+    assert d.find_block() and d.find_filename() and d.get_filename() == files[1][0]
+
+
+@pytest.mark.gpu
 def test_extract_reports_a_damaged_payload(zpq, gpu_ctx):
     files = [("a", "5000 bytes", INPUTS["lcg4k"] + bytes(904)), ("b", "12 bytes", b"Hello World!")]
     arc = bytearray(zpq.archive_add(gpu_ctx, 2, files))

@@ -65,6 +65,7 @@ def lib():
     L.zpq_sha1_blocks_dev.argtypes = [vp, i32, vp, vp, vp]
     L.zpq_sha1_ranges_dev.argtypes = [vp, i32, vp, vp, vp, vp]
     L.zpq_ctx_device.argtypes = [vp]
+    L.zpq_gather_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.zpq_block_create.argtypes = [vp, vp, vp]
     L.zpq_block_destroy.argtypes = [vp]
     L.zpq_block_encode_segment.argtypes = [vp, u8p, C.c_size_t, u32, vp, C.c_size_t, vp]

@@ -401,6 +401,31 @@ extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, co
                       final_code, first_byte, status, nullptr, nullptr, 0, nullptr, 0);
 }
 
+// ------------------------------------------------------------------ slab compaction
+// out_len[b] bytes of each capacity-strided output slab -> one dense buffer, so that only real
+// payload bytes cross PCIe.  One workgroup per block, 16-byte moves once the destination is aligned.
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
+                                                uint8_t *dst, const uint64_t *dst_off, int n)
+{
+    const int b = blockIdx.x;
+    if (b >= n) return;
+    const uint8_t *s = src + src_off[b];
+    uint8_t *d = dst + dst_off[b];
+    const uint32_t L = len[b];
+    for (uint32_t i = threadIdx.x; i < L; i += 256) d[i] = s[i];
+}
+
+extern "C" int zpq_gather_dev(zpq_ctx *c, int nblocks, const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
+                              uint8_t *dst, const uint64_t *dst_off)
+{
+    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (nblocks == 0) return ZPQ_OK;
+    if (!src_off || !len || !dst_off) return ZPQ_E_ARG;
+    HIPCK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_gather, dim3(nblocks), dim3(256), 0, c->stream, src, src_off, len, dst, dst_off, nblocks);
+    return hipGetLastError() == hipSuccess ? ZPQ_OK : ZPQ_E_INTERNAL;
+}
+
 // ------------------------------------------------------------------ SHA-1 side kernel (sha1.v:6-146)
 extern "C" int zpq_sha1_blocks_dev(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20)
 {

@@ -64,6 +64,11 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
     if (!archive || level < 0 || level > 5) return ZPQ_E_ARG;
     VecWriter w(archive);
     const int n = (int)files.size();
+    {
+        size_t guess = archive->size();
+        for (const ArchiveFile &f : files) guess += f.data.size() / 2 + f.name.size() + f.comment.size() + 128;
+        archive->reserve(guess);
+    }
     if (n == 0) return ZPQ_OK;
     if (level == 0) {                                   // store mode has no coder: host only (compressor.v:297-354)
         for (const ArchiveFile &f : files) {
@@ -121,12 +126,29 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
         return rc;
     std::vector<uint32_t> lens((size_t)n);
     std::vector<int32_t> st((size_t)n);
-    std::vector<uint8_t> sha((size_t)n * 20), coded((size_t)out_total);
+    std::vector<uint8_t> sha((size_t)n * 20);
     HK(hipMemcpyAsync(lens.data(), d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HK(hipMemcpyAsync(st.data(), d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (gpu_sha) HK(hipMemcpyAsync(sha.data(), d_sha.p, (size_t)n * 20, hipMemcpyDeviceToHost, s));
-    HK(hipMemcpyAsync(coded.data(), d_out.p, (size_t)out_total, hipMemcpyDeviceToHost, s));
     HK(hipStreamSynchronize(s));
+    // the slabs are capacity-strided: pack the real payload bytes on the device, download only those
+    std::vector<uint64_t> pk_off((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+        if (st[i] != ZPQ_OK) { lens[i] = 0; }
+        pk_off[i + 1] = pk_off[i] + lens[i];
+    }
+    std::vector<uint8_t> coded((size_t)pk_off[n]);
+    {
+        DevMem d_pk, d_pkoff, d_len2;
+        if ((rc = d_pk.alloc(pk_off[n] + 64)) || (rc = d_pkoff.alloc(((size_t)n + 1) * 8)) || (rc = d_len2.alloc((size_t)n * 4))) return rc;
+        HK(hipMemcpyAsync(d_pkoff.p, pk_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+        HK(hipMemcpyAsync(d_len2.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        if ((rc = zpq_gather_dev(ctx, n, d_out.as<uint8_t>(), d_outoff.as<uint64_t>(), d_len2.as<uint32_t>(), d_pk.as<uint8_t>(),
+                                 d_pkoff.as<uint64_t>())) != ZPQ_OK)
+            return rc;
+        if (!coded.empty()) HK(hipMemcpyAsync(coded.data(), d_pk.p, coded.size(), hipMemcpyDeviceToHost, s));
+        HK(hipStreamSynchronize(s));
+    }
     if (!gpu_sha) for (int i = 0; i < n; i++) host_sha1(files[i].data.data(), files[i].data.size(), &sha[(size_t)i * 20]);
 
     // a payload that outgrew its slab (possible: worst case ~16x) is coded again alone
@@ -148,7 +170,7 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
         framing::segment_header(w, files[i].name, files[i].comment);
         auto it = redo.find(i);
         if (it != redo.end()) w.write(it->second.data(), (int)it->second.size());
-        else w.write(coded.data() + out_off[i], (int)lens[i]);
+        else w.write(coded.data() + pk_off[i], (int)lens[i]);
         framing::segment_trailer(w, &sha[(size_t)i * 20]);
         framing::block_end(w);
     }
@@ -173,14 +195,21 @@ struct BlockRec {
 // find_block (decompressor.v:219-346) on a flat buffer: false = the reference's loop would stop here
 bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b)
 {
-    uint32_t h1 = 0x3D49B113u, h2 = 0x29EB7F93u, h3 = 0x2614BE13u, h4 = 0x3828EB13u;   // decompressor.v:227-236
-    for (;;) {
-        if (pos >= n) return false;
-        const uint32_t c = a[pos++];
-        h1 = h1 * 12 + c; h2 = h2 * 20 + c; h3 = h3 * 28 + c; h4 = h4 * 44 + c;
-        if (h1 == 0xB16B88F1u && h2 == 0xFF5376F1u && h3 == 0x72AC5BF1u && h4 == 0x2F909AF1u) break;
+    // The reference rolls four 32-bit hashes h = h*{12,20,28,44} + c over the stream and stops when all
+    // four hit their targets (decompressor.v:227-241).  12^16 = 20^16 = 28^16 = 44^16 = 0 (mod 2^32), so the
+    // hashes are a function of the last 16 bytes only, and the targets are the hashes of the 13-byte
+    // locator + "zPQ"; the initial constants are the state after the 13 locator bytes, so a stream that
+    // starts with "zPQ" matches too.  Searching for those bytes is the same test (up to a 128-bit hash
+    // collision) at memmem speed instead of 16 multiplies per archive byte.
+    static const uint8_t tag16[16] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3, 0x7a, 0x50, 0x51};
+    if (pos >= n) return false;
+    if (pos + 3 <= n && memcmp(a + pos, tag16 + 13, 3) == 0) { b.tag_pos = pos; pos += 3; }
+    else {
+        const void *m = memmem(a + pos, n - pos, tag16, sizeof tag16);
+        if (!m) { pos = n; return false; }
+        b.tag_pos = (size_t)(static_cast<const uint8_t *>(m) - a);
+        pos = b.tag_pos + 16;
     }
-    b.tag_pos = pos >= 16 ? pos - 16 : 0;              // the four hashes forget everything older than 16 bytes
     auto get = [&]() -> int { return pos < n ? a[pos++] : -1; };
     const int level = get();
     if (level != 1 && level != 2) return false;
