@@ -13,7 +13,7 @@ import oracle_lib as O
 import workload as W
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-from inputs import INPUTS  # noqa: E402
+from inputs import C4B, INPUTS  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
@@ -284,3 +284,22 @@ def test_level5_uses_compact_store_and_matches_oracle(zpq, gpu_ctx):
     assert coded[:6] == want and coded[6:12] == want       # same content -> same stream in any slot
     dec, status, *_ = gpu_ctx.decode_blocks(model, coded[:12], cap=65536)
     assert (status == 0).all() and dec == blocks[:12]
+
+
+def test_back_to_back_launches_do_not_see_each_others_state(zpq, gpu_ctx):
+    """The slot pool is reused by every launch and by every kernel family: results must not depend on what
+    the pool held before (in-kernel re-initialisation), nor on another kernel having used it in between."""
+    import workload as W
+    model = zpq.Model(level=2)
+    c4b = zpq.Model(header=C4B)
+    for rnd_ in range(5):
+        blocks = [bytes(W.make_block(64 * rnd_ + b, 3000 + 17 * b)) for b in range(40)]
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name.startswith("k_chain")
+        assert (status == 0).all()
+        assert coded == O.encode_blocks(model.header, blocks, nthreads=4)
+        if rnd_ == 2:                                       # another kernel works in pool 0 in between
+            other, st2, _ = gpu_ctx.encode_blocks(c4b, blocks[:3])
+            assert (st2 == 0).all() and other == O.encode_blocks(C4B, blocks[:3])
+        dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=4096)
+        assert (status == 0).all() and dec == blocks
