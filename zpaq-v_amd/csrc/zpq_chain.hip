@@ -162,6 +162,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
     const u8 *s_ns = lds + LDS_NS;
 
+    // stretch(cm >> 8) from the 8.5 KiB LDS packing (predictor.v:205-214); `cm` may be any u32
+    auto stretch_of = [&](u32 cm) -> i32 {
+        u32 q = cm >> 8;
+        q = min(max(q, 1u), 32767u);
+        const u32 wv = s_stretch[q >> 4];
+        const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+        const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+        const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+        return (q < 64u || q >= 32704u) ? endv : midv;
+    };
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / G, li = lane % G;
     const int row_base = lane & ~(G - 1);
@@ -190,13 +200,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     u8 *sp_lines = slot + C.sp_line_off;
     const u32 sp_mask = sp_log2 ? ((1u << sp_log2) - 1u) : 0u;
     const int sizebits = C.a + 2;
-    // Packed per-block state: ICM cm[256] as u32; ISSE weights are 20-bit two's complement
-    // (clamp512k, predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.
-    // Lanes without a table (idle, MIX2, and the ICM's missing t8) use per-workgroup dummy
-    // tables, so the bit loop needs no role branches.
+    // Packed per-block state.  ISSE weights are 20-bit two's complement (clamp512k,
+    // predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.  An ICM entry is
+    // its 23-bit cm[s] PLUS stretch(cm[s] >> 8) (12 bits), refreshed when the entry is trained:
+    // t32[s] = cm | (st & 0x1FF) << 23, t8[s] = st >> 9 -- the table lookup behind stretch then sits
+    // in the update phase instead of in front of the prediction chain.  Lanes without a table
+    // (idle, MIX2) use per-workgroup dummy tables, so the bit loop needs no role branches.
     u8 *dummy = lds + LDS_STATE + cfg.lds_dummy;
     u32 *t32 = reinterpret_cast<u32 *>(hashed ? my + cfg.lds_off32[li] : dummy);
-    u8 *t8 = is_isse ? my + cfg.lds_off8[li] : dummy + 1024;
+    u8 *t8 = hashed ? my + cfg.lds_off8[li] : dummy + 1024;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const int mix_j = M.comp[last].j, mix_k = M.comp[last].k, mix_rate = M.comp[last].rate;
     const u32 mix_mask = (u32)M.comp[last].mask, mix_cmask = (u32)(M.comp[last].c - 1);
@@ -211,7 +223,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             for (int c = 0; c < n; c++) {
                 const DComp &cc = M.comp[c];
                 u32 *d32 = reinterpret_cast<u32 *>(my + cfg.lds_off32[c]);
-                if (cc.type == ZT_ICM) for (int i = li; i < 256; i += G) d32[i] = B.img[i];
+                if (cc.type == ZT_ICM) {
+                    u8 *d8 = my + cfg.lds_off8[c];
+                    for (int i = li; i < 256; i += G) {
+                        const u32 cmi = B.img[i];                          // cminit(i) (statetable.v:108-116), < 2^23
+                        const i32 sti = stretch_of(cmi);
+                        d32[i] = cmi | (((u32)sti & 0x1FFu) << 23);
+                        d8[i] = (u8)(sti >> 9);
+                    }
+                }
                 else if (cc.type == ZT_ISSE) {
                     u8 *d8 = my + cfg.lds_off8[c];
                     for (int i = li; i < 256; i += G) {
@@ -275,16 +295,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u32 ch = 0;
         u8 *raddr = ht;
 
-        // stretch(cm >> 8) from the 8.5 KiB LDS packing (predictor.v:205-214); `cm` may be any u32
-        auto stretch_lds = [&](u32 cm) -> i32 {
-            u32 q = cm >> 8;
-            q = min(max(q, 1u), 32767u);
-            const u32 wv = s_stretch[q >> 4];
-            const u32 ei = q < 64u ? q : (q - 32704u + 64u);
-            const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
-            const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
-            return (q < 64u || q >= 32704u) ? endv : midv;
-        };
+        auto stretch_lds = stretch_of;
+        // the stretch an ICM entry carries (meaningless on other lanes, where it is masked out)
+        auto icm_st = [](u32 v, i32 b) -> i32 { return (i32)((u32)b << 9) | (i32)(v >> 23); };
         // decoded bit from lane `last` to the lanes below it: log-step DPP row_shl, no LDS round trip
         const int bdist = last - li;                       // > 0 on lanes that need the value
         auto bcast_down = [&](i32 v) -> i32 {
@@ -442,7 +455,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             cur_s = (X.r0 >> 8) & 255u;
             cur_v = t32[cur_s];
             cur_b = (i32)(int8_t)t8[cur_s];
-            cur_pst = stretch_lds(cur_v);
+            cur_pst = icm_st(cur_v, cur_b);
         };
 
         auto bitstep = [&](auto kc, const int bit) {
@@ -453,7 +466,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 cur_s = (dp >> shp) & 255u;
                 cur_v = t32[cur_s];
                 cur_b = (i32)(int8_t)t8[cur_s];
-                cur_pst = stretch_lds(cur_v);
+                cur_pst = icm_st(cur_v, cur_b);
             }
             const u32 s = cur_s;
             const i32 yk = DEC ? 0 : (i32)((ch >> bit) & 1u);  // encode knows its bit up front
@@ -474,7 +487,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
             const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);   // next state for y=0 | y=1 << 8
             // ---- (2) predict: chain p0 -> p1 -> ... (predictor.v:555-563,615-631)
-            const u32 cmv = cur_v;                                               // ICM lanes
+            const u32 cmv = cur_v & 0x7FFFFFu;                                   // ICM lanes
             const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE lanes: sext20
             const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
             i32 p = is_icm ? cur_pst : 0, pin = 0;
@@ -507,13 +520,17 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             //          outcomes, with this bit's cm update forwarded when the state repeats
             const u32 cm0 = (u32)wadd((i32)cmv, (0 - (i32)(cmv >> 8)) >> 2);       // y = 0 (predictor.v:706-708)
             const u32 cm1 = (u32)wadd((i32)cmv, (32767 - (i32)(cmv >> 8)) >> 2);   // y = 1
-            i32 stA = 0, stB = 0;
+            // the trained entry's stretch travels with it; encode knows y already, so it is computed here,
+            // off the path to the coder; decode computes it after the bit is known
+            i32 stA = 0, stB = 0, st0 = 0, st1 = 0, st_new = 0;
+            if (!DEC) st_new = stretch_lds(yk ? cm1 : cm0);
+            else if (SPEC) { st0 = stretch_lds(cm0); st1 = stretch_lds(cm1); }
             if (SPEC && K < 3) {
                 if (DEC) {
-                    stA = stretch_lds(sA == s ? cm0 : rAv);
-                    stB = stretch_lds(sB == s ? cm1 : rBv);
+                    stA = sA == s ? st0 : icm_st(rAv, rAb);
+                    stB = sB == s ? st1 : icm_st(rBv, rBb);
                 } else {
-                    stA = stretch_lds(sA == s ? (yk ? cm1 : cm0) : rAv);
+                    stA = sA == s ? st_new : icm_st(rAv, rAb);
                 }
             }
             // ---- (4) code the bit on the lane that owns the final prediction
@@ -542,8 +559,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 err = (y ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-            const u32 nv = is_icm ? (y ? cm1 : cm0) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
-            const i32 nb = nw1 >> 12;
+            if (DEC) st_new = SPEC ? (y ? st1 : st0) : stretch_lds(y ? cm1 : cm0);
+            const u32 nv = is_icm ? ((y ? cm1 : cm0) | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
+            const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
             t32[s] = nv;
             t8[s] = (u8)nb;
             if (has_mix2 && ctype == ZT_MIX2) {
@@ -707,6 +725,7 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     if (M->comp[0].type != ZT_ICM) return false;
     for (int c = 0; c < zpqc::G; c++) cfg->lds_off8[c] = 0xFFFF;
     cfg->lds_off32[0] = (uint16_t)place(1024, 0);
+    cfg->lds_off8[0] = (uint16_t)place(256, 0);                // the ICM's stretch high bits
     for (i = 1; i < M->n && M->comp[i].type == ZT_ISSE; i++) {
         if (M->comp[i].b != i - 1) return false;               // chain: ISSE i is fed by component i-1
         cfg->lds_off32[i] = (uint16_t)place(1024, i);
