@@ -1,0 +1,81 @@
+"""Malformed input must come back as a status code (or an empty result), never as a crash: the host-side
+parsers of the boundary -- header scan, model walk, block/segment framing reader -- fed with random and
+mutated bytes.  CPU only (no ctx): store-mode archives exercise the whole extract path; modelled blocks
+stop at 'no device', which is itself the documented behaviour."""
+import ctypes as C
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import oracle_lib as O  # noqa: E402
+
+
+def test_scan_and_model_walk_survive_random_headers(zpq):
+    rnd = random.Random(1234)
+    seen = {0: 0}
+    for trial in range(3000):
+        n = rnd.choice([0, 1, 4, 5, 6, 8, 12, 20, 40, 70, 200])
+        if trial % 3 == 0:                                     # mutate a real header
+            h = bytearray(zpq.level_header(rnd.randint(1, 5)))
+            for _ in range(rnd.randint(1, 4)):
+                if h:
+                    h[rnd.randrange(len(h))] = rnd.getrandbits(8)
+            h = bytes(h[:rnd.randint(0, len(h))]) if trial % 2 else bytes(h)
+        else:
+            h = bytes(rnd.getrandbits(8) for _ in range(n))
+        offs = zpq.scan_header(h)
+        assert offs == O.scan_header(h)                        # same quirks as the restated scanner
+        try:
+            m = zpq.Model(header=h, offsets=offs)
+            seen[0] += 1
+            assert 0 <= m.ncomp <= 255 and m.state_bytes >= 0
+        except zpq.ZpqError as e:
+            assert e.code < 0
+            seen[e.code] = seen.get(e.code, 0) + 1
+    assert seen[0] > 50 and len(seen) >= 2                     # both outcomes were exercised
+
+
+def test_archive_reader_survives_garbage_and_mutations(zpq):
+    rnd = random.Random(99)
+    files = [("a.txt", "11 bytes", b"hello world"), ("b", "0 bytes", b""), ("c.bin", "300 bytes", bytes(range(256)) + bytes(44))]
+    good = zpq.archive_add(None, 0, files)
+    assert [(g["name"], g["data"]) for g in zpq.archive_extract(None, good)] == [(f[0], f[2]) for f in files]
+    for trial in range(400):
+        kind = trial % 4
+        if kind == 0:
+            arc = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 1, 15, 16, 17, 100, 1000])))
+        elif kind == 1:
+            arc = good[:rnd.randint(0, len(good))]                                    # truncation anywhere
+        elif kind == 2:
+            b = bytearray(good)
+            for _ in range(rnd.randint(1, 6)):
+                b[rnd.randrange(len(b))] = rnd.getrandbits(8)
+            arc = bytes(b)
+        else:                                                                          # a modelled block, but no device
+            buf = C.create_string_buffer(4096)
+            k = O.lib().zo_compress_archive(rnd.randint(1, 3), b"m", b"3 bytes", b"abc", 3, 1, buf, len(buf))
+            arc = good[:rnd.choice([0, len(good)])] + buf.raw[:k] + good
+        out = zpq.archive_extract(None, arc)
+        assert isinstance(out, list)
+        if kind == 3:                                          # the modelled block is reported, the store blocks still come out
+            assert any(g["status"] == -1 for g in out) and [g["name"] for g in out if g["status"] == 0][-3:] == ["a.txt", "b", "c.bin"]
+        for g in out:
+            assert g["size"] == len(g["data"]) and g["size"] < 10 * len(good) + 1000
+
+
+def test_cli_rejects_bad_usage_without_crashing(tmp_path):
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zpaq-v_amd", "bin", "zpaqv")
+    for args, needle in (([], "Missing command"), (["q", "x"], "Unknown command"), (["a"], "Missing archive name"),
+                         (["x", str(tmp_path / "nope")], "not found"), (["a", str(tmp_path / "arc"), "-bogus"], "Unknown option"),
+                         (["a", str(tmp_path / "arc"), str(tmp_path / "missing-file")], "No files to add")):
+        r = subprocess.run([cli] + args, capture_output=True, text=True)
+        assert r.returncode == 1 and needle in r.stderr, (args, r.stderr)
+    r = subprocess.run([cli, "help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage" in r.stdout
+    (tmp_path / "junk.zpaq").write_bytes(os.urandom(5000))
+    r = subprocess.run([cli, "l", str(tmp_path / "junk")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Total files: 0" in r.stdout
