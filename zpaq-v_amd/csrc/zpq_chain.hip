@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const bool has_mix2 = NCH ? MIXT : (cfg.has_mix2 != 0);
     const int ctype = (li < n) ? M.comp[li].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
-    const bool is_icm = ctype == ZT_ICM, is_isse = ctype == ZT_ISSE, is_last = li == last;
+    const bool is_icm = ctype == ZT_ICM, is_last = li == last;
     const DComp &C = M.comp[li < n ? li : 0];
     // lanes without a hash table (idle, MIX2) run the same row loads against the first 64
     // bytes of the slot: no exec-masked branch around the loads (a branch join would make
@@ -460,14 +460,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
         auto bitstep = [&](auto kc, const int bit) {
             constexpr int K = decltype(kc)::value;
-            if (!SPEC && K > 0) {                              // plain form: this bit's state from the row
-                const u32 shp = (X.slot & 3u) * 8u;
-                const u32 dp = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
-                cur_s = (dp >> shp) & 255u;
-                cur_v = t32[cur_s];
-                cur_b = (i32)(int8_t)t8[cur_s];
-                cur_pst = icm_st(cur_v, cur_b);
-            }
+            // (plain form: cur_* of bits 1..3 were fetched at the end of the previous bit step, see (4b))
             const u32 s = cur_s;
             const i32 yk = DEC ? 0 : (i32)((ch >> bit) & 1u);  // encode knows its bit up front
             // ---- (1) next bit's candidate states and their table entries, read BEFORE this
@@ -555,11 +548,26 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 if (bit == 4) prefetch_rows(hctx, c8n);
                 else { hnext_dec = run_vm(c8n - 256u); prefetch_rows(hnext_dec, 1u); }
             }
+            // ---- (4b) plain form: the bit is known, so is the next slot (2*slot + y).  Fetch the next bit's
+            //           entry NOW, before this bit's update is computed and stored -- otherwise the read
+            //           would queue behind the store and behind the update's own stretch lookup (two
+            //           LDS round trips in series).  The update is forwarded in (6) when the state repeats.
+            u32 sN = 0, rNv = 0;
+            i32 rNb = 0;
+            if (!SPEC && K < 3) {
+                u32 pair;
+                if (K == 0) pair = X.r0 >> 16;
+                else if (K == 1) pair = X.r1 >> ((X.slot & 1u) * 16u);
+                else pair = ((X.slot & 2u) ? X.r3 : X.r2) >> ((X.slot & 1u) * 16u);
+                sN = y ? ((pair >> 8) & 255u) : (pair & 255u);
+                rNv = t32[sN];
+                rNb = (i32)(int8_t)t8[sN];
+            }
             // ---- (5) update (predictor.v:701-709,776-791): one 8-byte LDS store per lane
             const i32 err = (y ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-            if (DEC) st_new = SPEC ? (y ? st1 : st0) : stretch_lds(y ? cm1 : cm0);
+            if (DEC) st_new = SPEC ? (y ? st1 : st0) : stretch_lds(y ? cm1 : cm0);   // (both outcomes ahead of the coder: measured slower)
             const u32 nv = is_icm ? ((y ? cm1 : cm0) | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
             const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
             t32[s] = nv;
@@ -580,6 +588,13 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 cur_b = same ? nb : rb;
                 cur_pst = DEC ? (y ? stB : stA) : stA;
                 cur_s = sn;
+            }
+            if (!SPEC && K < 3) {
+                const bool same = sN == s;
+                cur_v = same ? nv : rNv;
+                cur_b = same ? nb : rNb;
+                cur_pst = icm_st(cur_v, cur_b);
+                cur_s = sN;
             }
             // next bit-history state into the row (statetable.v:75-84)
             const u32 nsv = y ? (ns01 >> 8) : (ns01 & 255u);
