@@ -301,6 +301,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // decoded bit from lane `last` to the lanes below it: log-step DPP row_shl, no LDS round trip
         const int bdist = last - li;                       // > 0 on lanes that need the value
         auto bcast_down = [&](i32 v) -> i32 {
+            if constexpr (NCH > 0 && NCH + (MIXT ? 1 : 0) <= 4) {
+                // all of the block's lanes are in one quad: one quad_perm broadcast of the coder lane
+                constexpr int L = NCH + (MIXT ? 1 : 0) - 1;
+                return __builtin_amdgcn_update_dpp(v, v, L * 0x55 /*quad_perm:[L,L,L,L]*/, 0xf, 0xf, false);
+            }
             if (n > 1) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x101 /*row_shl:1*/, 0xf, 0xf, false); v = (bdist == 1) ? t : v; }
             if (n > 2) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x102 /*row_shl:2*/, 0xf, 0xf, false); v = (bdist >= 2 && bdist < 4) ? t : v; }
             if (n > 4) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0xf, false); v = (bdist >= 4 && bdist < 8) ? t : v; }
