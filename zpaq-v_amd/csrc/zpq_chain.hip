@@ -4,21 +4,26 @@
 // (levels.v:53-375: level 1 = ICM+ISSE ... level 5 = ICM+7xISSE+MIX2).
 //
 // Mapping (gfx950, wave64):
-//   * one ZPAQ block = one GROUP of G=16 lanes (one DPP row); a wave carries 4
-//     blocks, a workgroup W waves.  Lane c of a group owns component c.
-//   * per block in LDS: ICM cm[256] (1 KiB) and each ISSE's 256 weight pairs packed
-//     to 20+20 bits (1.25 KiB): 3.5 KiB per level-2 block, 32 blocks per CU.  Shared per workgroup in LDS: squash (i16[4096]), the
-//     state table ns[1024] and a 8.5 KiB packing of the 64 KiB stretch table.
-//   * per block in HBM (its state slot): the hash tables (64*2^sizebits bytes per
-//     component), M/H for the ZPAQL VM, MIX2 weights.  A nibble's bit-history
-//     row (16 B: check byte + 15 states) is fetched as h0 / h0^16 / h0^32 from
-//     ONE 64-byte line, kept in 4 VGPRs for the nibble's four bits, and written
+//   * one ZPAQ block = one GROUP of G lanes inside a DPP row (G = 8 for models with <= 8
+//     components, else 16); a wave carries 64/G blocks, a workgroup up to 32 blocks (= one CU's
+//     LDS).  Lane c of a group owns component c.
+//   * per block in LDS: the ICM's 256 entries (23-bit cm + its 12-bit stretch = u32 + u8) and each
+//     ISSE's 256 weight pairs packed to 20+20 bits (u32 + u8): 3.75 KiB per level-2 block, 32 blocks
+//     per CU.  Shared per workgroup in LDS: squash (u16[4096]), the state table ns[1024] and an
+//     8.5 KiB packing of the 64 KiB stretch table.
+//   * per block in HBM (its state slot): the hash tables (64*2^sizebits bytes per component, or a
+//     compact line store for levels 4-5), M/H for the ZPAQL VM, MIX2 weights.  A nibble's
+//     bit-history row (16 B: check byte + 15 states) is fetched as h0 / h0^16 / h0^32 from ONE
+//     64-byte line AHEAD of the nibble that uses it, kept in 4 VGPRs for the nibble's four bits
+//     (the nibble is unrolled so the dword holding the slot is a compile-time choice), and written
 //     back once (predictor.v:495-532,558-563,619-622,704,790).
-//   * the prediction chain p0 -> p1 -> ... is handed lane-to-lane with DPP
-//     row_shr:1; the final probability and (when decoding) the decoded bit are
-//     broadcast inside the row with ds_bpermute.
-//   * the arithmetic coder (encoder.v:48-89 / decoder.v:73-118) runs on the lane
-//     that owns the last component.
+//   * the prediction chain p0 -> p1 -> ... is handed lane-to-lane with DPP row_shr:1; the decoded
+//     bit goes back down the row by DPP (one quad_perm for <= 4 components); MIX2 inputs by
+//     ds_bpermute.
+//   * the arithmetic coder (encoder.v:48-89 / decoder.v:73-118) runs on the lane that owns the
+//     last component.
+//   * encode: software-pipelined bit step (next bit's entry fetched before this bit's update,
+//     forwarded on a state match); decode: the next entry is fetched the moment the bit is known.
 // All arithmetic is integer and reproduces V's 32-bit wrap/arithmetic-shift
 // semantics; results are bit-identical to zpq_generic.hip and the CPU oracle.
 #include <hip/hip_runtime.h>
@@ -33,13 +38,10 @@
 #include "zpq_vm.h"
 #include "zpq_host.h"
 
-// Measured on MI355X at two waves per SIMD (profiles/r01): the pipelined step wins for
-// encode (364 vs 373 ms), the plain one for decode (427 vs 456 ms).
+// Measured on MI355X: the pipelined step wins for encode, for decode the step with
+// fewer instructions wins (both-candidate speculation was slower every time it was tried).
 #ifndef ZPQ_CHAIN_G_DEFAULT
 #define ZPQ_CHAIN_G_DEFAULT 8
-#endif
-#ifndef ZPQ_CHAIN_DEC_WARM
-#define ZPQ_CHAIN_DEC_WARM 0   /* measured: 352 -> 379 ms at 8192 blocks (traffic x5 on row lines) */
 #endif
 #ifndef ZPQ_CHAIN_SPEC_ENC
 #define ZPQ_CHAIN_SPEC_ENC 1
@@ -142,7 +144,6 @@ template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     constexpr int G = GG;            // shadows zpqc::G inside the kernel
-    constexpr bool WARM = ZPQ_CHAIN_DEC_WARM != 0;
     constexpr int BPW = 64 / GG;
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -384,45 +385,6 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(paddr2) : "v"(X.r0), "v"(X.r3));
             if (have_prev && hashed) *reinterpret_cast<u32x4 *>(paddr2) = Rp;
         };
-        // Side-effect-free preview of run_vm for the two register-evaluated program shapes
-        // (used by the decoder to warm candidate rows before the byte is fully known)
-        auto peek_vm = [&](const u32 byte) -> u32 {
-            u32 hv = 0;
-            if (cfg.vm_kind == VM_HASHCHAIN) {
-                u32 a = byte;
-                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
-            } else {
-                const u32 mm = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
-                u32 bb = b4, a = 0;
-                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
-                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
-                const u32 h0v = a; bb--;
-                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
-                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
-                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
-            }
-            return hv;
-        };
-        // decode: cache-warming loads of the 4 candidate lines once 2 bits of a nibble are known.
-        // The values are never used for coding; they are folded into `junk` after the next real
-        // row loads have been waited for (so no extra wait) to keep the loads alive.
-        u32 junk = 0, wm0 = 0, wm1 = 0, wm2 = 0, wm3 = 0;
-        auto warm4 = [&](const u32 cx0, const u32 cx1, const u32 cx2, const u32 cx3) {
-            wm0 = *reinterpret_cast<const u32 *>(ht + ((cx0 * 16u) & ht_mask));
-            wm1 = *reinterpret_cast<const u32 *>(ht + ((cx1 * 16u) & ht_mask));
-            wm2 = *reinterpret_cast<const u32 *>(ht + ((cx2 * 16u) & ht_mask));
-            wm3 = *reinterpret_cast<const u32 *>(ht + ((cx3 * 16u) & ht_mask));
-        };
-        auto warm_nibble2 = [&]() {                          // X.c8 = 1ab: second-nibble contexts 1ab00..1ab11
-            const u32 c = X.c8 << 2;
-            warm4(hctx + 16u * c, hctx + 16u * (c | 1u), hctx + 16u * (c | 2u), hctx + 16u * (c | 3u));
-        };
-        auto warm_next_byte = [&]() {                        // X.c8 = 1hhhhab: 4 candidate bytes
-            if (cfg.vm_kind != VM_GENERIC) {
-                const u32 b0 = (X.c8 << 2) - 256u;
-                warm4(peek_vm(b0) + 16u, peek_vm(b0 + 1u) + 16u, peek_vm(b0 + 2u) + 16u, peek_vm(b0 + 3u) + 16u);
-            }
-        };
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
         auto run_vm = [&](const u32 byte) -> u32 {
             u32 hv = 0;
@@ -655,7 +617,6 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 7);
             bitstep(std::integral_constant<int, 1>{}, 6);
-            if (DEC && WARM) { junk ^= wm0 ^ wm1 ^ wm2 ^ wm3; warm_nibble2(); }
             bitstep(std::integral_constant<int, 2>{}, 5);
             bitstep(std::integral_constant<int, 3>{}, 4);     // decode: requests the next rows inside
             take_prefetched(true);
@@ -663,7 +624,6 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, 3);
             bitstep(std::integral_constant<int, 1>{}, 2);
-            if (DEC && WARM) { junk ^= wm0 ^ wm1 ^ wm2 ^ wm3; warm_next_byte(); }
             bitstep(std::integral_constant<int, 2>{}, 1);
             bitstep(std::integral_constant<int, 3>{}, 0);
             const u32 byte = X.c8 - 256;
@@ -693,7 +653,6 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 X.opos++;
             }
         }
-        if (DEC && WARM && (junk ^ wm0 ^ wm1 ^ wm2 ^ wm3) == 0x9E3779B9u && nin == 0xFFFFFFFFu) status = (i32)junk;  // never true: keeps the warming loads
         i32 st0 = row_bcast(status, row_base);                 // VM status lives on lane 0
         for (int c = 1; c < n; c++) { const i32 sc = row_bcast(status, row_base + c); st0 = st0 ? st0 : sc; }   // line-store overflow: any hashed lane
         if (is_last) {
