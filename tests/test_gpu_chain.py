@@ -303,3 +303,44 @@ def test_back_to_back_launches_do_not_see_each_others_state(zpq, gpu_ctx):
             assert (st2 == 0).all() and other == O.encode_blocks(C4B, blocks[:3])
         dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=4096)
         assert (status == 0).all() and dec == blocks
+
+
+def _device_round_trip(zpq, ctx, model, arr, capmul, flags=None):
+    """encode + decode of a resident batch; returns (coded slabs as numpy, lens, cap) after the property checks."""
+    import torch
+    flags = zpq.FLAG_PP if flags is None else flags
+    nb, size = arr.shape
+    dev = torch.device("cuda:0")
+    cap = int(size * capmul) + 1024
+    d_in = torch.from_numpy(arr.reshape(-1)).to(dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    in_off = torch.arange(nb + 1, **i64) * size
+    out_off = torch.arange(nb + 1, **i64) * cap
+    d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
+    d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
+    d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), flags, d_out.data_ptr(),
+                          out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
+    ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), flags, d_dec.data_ptr(),
+                          in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
+                          d_first.data_ptr(), d_dst.data_ptr())
+    ctx.sync()
+    assert bool((d_st == 0).all()) and bool((d_dst == 0).all())
+    assert bool((d_dlen == size).all()) and bool((d_first == 0).all())
+    assert bool(torch.equal(d_dec, d_in)) and bool(torch.equal(d_cons, d_len)) and bool((d_code == -1).all())
+    return d_out.cpu().numpy(), d_len.cpu().numpy(), cap
+
+
+@pytest.mark.parametrize("level,nb", [(1, 2048), (3, 1024), (4, 512)])
+def test_other_levels_at_baseline_block_size(zpq, gpu_ctx, level, nb):
+    """64 KiB blocks of all four classes at the levels the headline test does not cover: round-trip
+    properties on every block, byte parity with the oracle on a sample."""
+    arr = W.make_blocks_fast(nb, 65536)
+    model = zpq.Model(level=level)
+    out, lens, cap = _device_round_trip(zpq, gpu_ctx, model, arr, 1.125)
+    assert gpu_ctx.last_kernel_name == "k_chain<decode>"
+    sample = [0, 1, 2, 3, nb // 2 + 1, nb - 2]
+    want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
+    for i, w in zip(sample, want):
+        assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i

@@ -157,3 +157,37 @@ def test_slot_reuse_and_overflow(zpq, gpu_ctx):
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
     _, status, out_len = gpu_ctx.encode_blocks(model, [INPUTS["lcg4k"]], cap=64)
     assert status[0] == -7 and int(out_len[0]) == len(O.Codec(C4B).encode(INPUTS["lcg4k"]))
+
+
+def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
+    """C4b (all nine component types) on 64 KiB blocks of all four classes through the lanes kernel:
+    round-trip properties on every block, byte parity with the oracle on a sample."""
+    import torch
+    import workload as W
+    nb, size = 256, 65536
+    arr = W.make_blocks_fast(nb, size)
+    model = zpq.Model(header=C4B)
+    dev = torch.device("cuda:0")
+    cap = size * 6 + 1024
+    d_in = torch.from_numpy(arr.reshape(-1)).to(dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    in_off = torch.arange(nb + 1, **i64) * size
+    out_off = torch.arange(nb + 1, **i64) * cap
+    d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
+    d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
+    d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
+                              out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
+    assert gpu_ctx.last_kernel_name == "k_lanes<encode>"
+    gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
+                              in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
+                              d_first.data_ptr(), d_dst.data_ptr())
+    gpu_ctx.sync()
+    assert bool((d_st == 0).all()) and bool((d_dst == 0).all()) and bool((d_dlen == size).all())
+    assert bool(torch.equal(d_dec, d_in)) and bool(torch.equal(d_cons, d_len)) and bool((d_first == 0).all())
+    out, lens = d_out.cpu().numpy(), d_len.cpu().numpy()
+    sample = [0, 1, 2, 3, 130, 255]
+    want = O.encode_blocks(C4B, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
+    for i, w in zip(sample, want):
+        assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i
