@@ -154,6 +154,7 @@ private:
     int err_;
     bool has_stored_sha1_;
     uint8_t stored_sha1_[20];
+    int header_n_, header_t0_;         // header[4], header[5]: handed to the PostProcessor as ph, pm
 };
 
 // ---- batch form of the reference CLI's loops (cmd/main.v:239-470) -------------------------------

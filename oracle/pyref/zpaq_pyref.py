@@ -393,8 +393,9 @@ class ZPAQL:
             z.r[operand & 255] = z.a
         elif op == 56:
             return False
-        elif op == 57:
-            pass  # OUT: appends to a host buffer only (zpaql.v:151-159)
+        elif op == 57:  # OUT: appends to a host buffer only (zpaql.v:151-159,382-384)
+            if getattr(z, "outbuf", None) is not None:
+                z.outbuf.append(z.a & 255)
         elif op == 59:
             z.a = u32((z.a + z.m_get(z.b) + 512) * 773)
         elif op == 60:
@@ -870,6 +871,85 @@ class Decoder:  # decoder.v
 
 
 # ---------------------------------------------------------------- drivers
+
+
+class PostProcessor:
+    """decompressor.v:14-167, byte for byte: (PASS=0 | PROG=1 psize[0..1] pcomp[0..psize-1]) data..."""
+
+    def __init__(self, ph=0, pm=0):  # PostProcessor.new + init (:26-43)
+        self.state = 0
+        self.hsize = 0
+        self.ph, self.pm = ph, pm
+        self.z = None
+        self.outbuf = bytearray()
+
+    def write(self, c):  # :55-152
+        if self.state == 0:
+            if c < 0:
+                return self.state
+            self.state = c + 1
+            if self.state > 2:
+                self.state = 1
+        elif self.state == 1:
+            if c >= 0:
+                self.outbuf.append(c)
+        elif self.state == 2:
+            if c < 0:
+                return self.state
+            self.hsize = c
+            self.state = 3
+        elif self.state == 3:
+            if c < 0:
+                return self.state
+            self.hsize += c * 256
+            if self.hsize < 1:
+                self.state = 1
+                return self.state
+            hdr = bytearray(self.hsize + 300)
+            hdr[4], hdr[5] = self.ph & 255, self.pm & 255
+            z = ZPAQL(b"", 8, 8 + 128, 8 + 128)      # fresh VM: no H, no M, registers 0
+            z.header = hdr
+            z.outbuf = []
+            self.z = z
+            self.state = 4
+        elif self.state == 4:
+            if c < 0:
+                return self.state
+            z = self.z
+            if z.hend < len(z.header):
+                z.header[z.hend] = c
+                z.hend += 1
+            if z.hend - z.hbegin == self.hsize:
+                total = z.cend - 2 + z.hend - z.hbegin
+                z.header[0] = total & 255
+                z.header[1] = (total >> 8) & 255
+                hm = z.header[1]                      # initp() (zpaql.v:86-95): M from header[1]; inith() is never called
+                if 0 < hm < 32:
+                    z.m = bytearray(1 << hm)
+                z.pc = z.hbegin
+                z.header = bytes(z.header)
+                self.state = 5
+        elif self.state == 5:
+            if c >= 0:
+                self.z.run(c)
+                self.outbuf.extend(self.z.outbuf)
+                self.z.outbuf = []
+        return self.state
+
+
+def postprocess(decoded, ph=0, pm=0):
+    """Everything Decoder.decompress() yields for one segment (mode byte first) -> the segment's output, the way
+    Decompresser.decompress drives the PostProcessor (decompressor.v:466-512)."""
+    pp = PostProcessor(ph, pm)
+    it = iter(decoded)
+    while (pp.state & 3) != 1:
+        c = next(it, -1)
+        if c < 0:
+            return b""
+        pp.write(c)
+    for c in it:
+        pp.write(c)
+    return bytes(pp.outbuf)
 
 
 def new_model(header, offsets=None):

@@ -192,3 +192,82 @@ def test_cli_level2_directory_round_trip_and_archive_bytes(tmp_path):
     assert r.returncode == 0 and "Files extracted: %d" % len(files) in r.stdout, r.stderr
     for nm, _, d in files:
         assert (out / nm).read_bytes() == d
+
+
+# ---------------------------------------------------------------- PostProcessor PROG mode (decompressor.v:14-167)
+def _prog_archive(zpq, ctx, level, name, stream, expect):
+    """An archive whose one segment decodes to `stream` (mode byte first): the framing of an ordinary block
+    around the coded stream, with the SHA-1 of the post-processed output as libzpaq writers store it."""
+    hdr = O.level_header(level)
+    shell = zpq.archive_add(ctx, level, [(name, "", b"")])
+    coded_empty = O.encode_blocks(hdr, [b""], pp=True)[0]
+    prefix = shell[:len(shell) - (len(coded_empty) + 4 + 21 + 1)]
+    coded = O.encode_blocks(hdr, [stream], pp=False)[0]
+    return prefix + coded + bytes(4) + b"\xfd" + hashlib.sha1(expect).digest() + b"\xff"
+
+
+def _jt_loop_program():
+    """c=a  a=3  d=a  L: a=c out d-- a=d a>0 jt L halt  -- every input byte three times."""
+    prog = [80, 71, 3, 88]
+    loop = len(prog)
+    prog += [66, 57, 26, 67, 239, 0]
+    jt = len(prog)
+    rel = loop - (jt + 2)                       # applied after the operand fetch, offset ((N+128)&255)-127 (quirk Q11)
+    prog += [39, (rel - 1) & 255, 56]
+    return prog
+
+
+PROGS = {
+    "identity": [57, 56],
+    "plus_one": [1, 57, 56],
+    "twice": [57, 57, 56],
+    "delay_no_m": [80, 68, 57, 66, 96, 56],                       # psize < 250: the PCOMP VM has no M -> zeros come out
+    "delay_with_m": [80, 68, 57, 66, 96, 56] + [0] * 250,         # (6 + psize) >> 8 == 1 -> M of 2 bytes exists
+    "loop_r": _jt_loop_program(),
+    "hashd_on_empty_h": [60, 64 + 6, 57, 56],                     # H is never allocated in the PostProcessor: *d reads 0
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(PROGS))
+def test_postprocessor_prog_mode(zpq, gpu_ctx, name):
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "pyref"))
+    import zpaq_pyref as P
+    prog = PROGS[name]
+    payload = INPUTS["text2k"][:700] + bytes(range(256))
+    stream = bytes([1, len(prog) & 255, len(prog) >> 8]) + bytes(prog) + payload
+    expect = P.postprocess(stream)
+    assert len(expect) >= len(payload) and (name != "identity" or expect == payload)
+    arc = _prog_archive(zpq, gpu_ctx, 2, "p.bin", stream, expect)
+    got = zpq.archive_extract(gpu_ctx, arc)
+    assert len(got) == 1 and got[0]["status"] == 0 and got[0]["name"] == "p.bin"
+    assert got[0]["data"] == expect and got[0]["sha1_ok"]
+    d = zpq.Decompresser(gpu_ctx)                                  # the sequential front end, 100 bytes at a time
+    d.set_input(arc)
+    assert d.find_block() and d.find_filename()
+    while d.decompress(100):
+        pass
+    assert d.output_bytes() == expect and d.last_error == 0
+
+
+@pytest.mark.gpu
+def test_postprocessor_mode_byte_corner_cases(zpq, gpu_ctx):
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "pyref"))
+    import zpaq_pyref as P
+    cases = {
+        "unknown mode is PASS": bytes([7]) + b"abcdef",
+        "PROG with size 0 is PASS": bytes([1, 0, 0]) + b"abcdef",
+        "stream ends inside the size": bytes([1, 5]),
+        "stream ends inside the program": bytes([1, 9, 0, 57, 56]),
+        "program only, no data": bytes([1, 2, 0, 57, 56]),
+    }
+    for what, stream in cases.items():
+        expect = P.postprocess(stream)
+        arc = _prog_archive(zpq, gpu_ctx, 1, "c", stream, expect)
+        got = zpq.archive_extract(gpu_ctx, arc)
+        assert [g["data"] for g in got] == [expect] and got[0]["status"] == 0, what
+    # a PCOMP program that never halts: the reference would hang; here the file carries a status
+    stream = bytes([1, 3, 0, 63, 0xFD, 56]) + b"x"               # jmp to itself: rel = ((0xFD + 128) & 255) - 127 = -2
+    arc = _prog_archive(zpq, gpu_ctx, 1, "hang", stream, b"")
+    got = zpq.archive_extract(gpu_ctx, arc)
+    assert got[0]["status"] == -8

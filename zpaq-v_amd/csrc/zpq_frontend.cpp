@@ -9,6 +9,7 @@
 // and the PostProcessor PASS state (decompressor.v:56-82).  All modelled coding goes to
 // the GPU through zpq_block_encode_segment / zpq_block_decode_segment.
 #include "../../include/zpaq_frontend.hpp"
+#include "zpq_vm.h"
 
 #include <string.h>
 
@@ -256,7 +257,7 @@ void Compressor::end_block()
 Decompresser::Decompresser(zpq_ctx *ctx)
     : state_(kStart), ctx_(ctx), model_(nullptr), block_(nullptr), input_(nullptr), output_(nullptr),
       pos_(0), slurped_(false), ncomp_(0), store_count_(0), first_seg_(true), decoded_(false),
-      seg_pos_(0), seg_empty_(false), final_code_(0), segs_in_block_(0), err_(ZPQ_OK), has_stored_sha1_(false)
+      seg_pos_(0), seg_empty_(false), final_code_(0), segs_in_block_(0), err_(ZPQ_OK), has_stored_sha1_(false), header_n_(0), header_t0_(0)
 {
 }
 Decompresser::~Decompresser() { drop_block(); }
@@ -319,6 +320,8 @@ bool Decompresser::find_block()
     for (int i = 0; i < hcomp_len; i++) { const int b = get(); if (b < 0) return false; hdr.push_back((uint8_t)b); }
     const int hend = (int)hdr.size() - 1;
     ncomp_ = n;
+    header_n_ = hdr.size() > 4 ? hdr[4] : 0;                // what the reference passes as "ph, pm": header[4], header[5]
+    header_t0_ = hdr.size() > 5 ? hdr[5] : 0;               // (decompressor.v:456-463); stored by the PostProcessor, never used
     segs_in_block_ = 0;
     drop_block();
     err_ = zpq_model_create(hdr.data(), (int)hdr.size(), cend, hbegin, hend, &model_);
@@ -364,6 +367,43 @@ bool Decompresser::find_filename()
     return true;
 }
 
+// PostProcessor.write() for a whole decoded segment in PROG mode (decompressor.v:55-152): `in` is
+// everything the decoder produced after the mode byte 1: psize lo, psize hi, psize PCOMP bytes, then the
+// data bytes, each of which is one run of the PCOMP program; its OUT bytes are the segment's output.
+// The reference's PostProcessor VM is set up in a peculiar way, kept as is: header = psize + 300 zero
+// bytes with cend = 8, hbegin = 136 and the program at 136..; header[0..1] = (6 + psize) lo/hi;
+// initp() then sizes M from header[1] (2^((6+psize) >> 8) bytes if that is 1..31, else no M at all) and
+// inith() is never called, so H stays empty (reads 0, writes ignored); ph/pm are stored and never used.
+// A size < 1 falls back to PASS (:97-100).  Returns a ZPQ_* status (ZPQ_E_VMSTEPS if a run does not end).
+static int postprocess_prog(const std::vector<uint8_t> &in, int ph, int pm, std::vector<uint8_t> *out)
+{
+    out->clear();
+    if (in.size() < 2) return ZPQ_OK;                   // EOS while reading the size: nothing is output (:85-96)
+    const int psize = in[0] + in[1] * 256;
+    if (psize < 1) { out->assign(in.begin() + 2, in.end()); return ZPQ_OK; }
+    if (in.size() < (size_t)psize + 2) return ZPQ_OK;   // EOS while loading the program (:115-118)
+    std::vector<uint8_t> header((size_t)psize + 300, 0);
+    const int hbegin = 8 + 128, hend = hbegin + psize, total = 8 - 2 + psize;
+    header[0] = (uint8_t)(total & 255);
+    header[1] = (uint8_t)(total >> 8);
+    header[4] = (uint8_t)ph;
+    header[5] = (uint8_t)pm;
+    memcpy(header.data() + hbegin, in.data() + 2, (size_t)psize);
+    const int hm = header[1];
+    std::vector<uint8_t> m((hm > 0 && hm < 32) ? ((size_t)1 << hm) : 0, 0);
+    std::vector<uint32_t> r(256, 0);
+    zpqvm::Vm z;
+    z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = hbegin;
+    z.m = m.data(); z.mlen = (uint32_t)m.size();
+    z.h = nullptr; z.hlen = 0;
+    z.r = r.data();
+    z.hdr = header.data(); z.hdr_len = (int32_t)header.size(); z.hbegin = hbegin; z.hend = hend;
+    z.out = out;
+    for (size_t i = (size_t)psize + 2; i < in.size(); i++)
+        if (!zpqvm::vm_run(z, in[i])) return ZPQ_E_VMSTEPS;
+    return ZPQ_OK;
+}
+
 // One GPU call decodes the whole segment (was: dec.decompress() per byte).
 bool Decompresser::decode_segment()
 {
@@ -389,8 +429,13 @@ bool Decompresser::decode_segment()
     segs_in_block_++;
     pos_ += consumed;
     seg_empty_ = (first == 0xFFFFFFFFu);
-    if (first == 1) { err_ = ZPQ_E_ARG; return false; }   // PostProcessor PROG mode: out of scope (never written)
-    seg_.assign(out.begin(), out.begin() + (ptrdiff_t)n);
+    if (first == 1) {                                       // PostProcessor PROG mode (decompressor.v:63,84-148)
+        const std::vector<uint8_t> coded_out(out.begin(), out.begin() + (ptrdiff_t)n);
+        err_ = postprocess_prog(coded_out, header_n_, header_t0_, &seg_);
+        if (err_ != ZPQ_OK) return false;
+    } else {
+        seg_.assign(out.begin(), out.begin() + (ptrdiff_t)n);  // PASS; a mode byte > 1 also means PASS (:64-66)
+    }
     seg_pos_ = 0;
     return true;
 }

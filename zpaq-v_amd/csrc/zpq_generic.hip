@@ -497,6 +497,7 @@ __global__ void __launch_bounds__(64) k_generic(const DBatch B)
         z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
         z.r = reinterpret_cast<u32 *>(slot + M.r_off);
         z.hdr = S.header; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
+        z.out = nullptr;
 
         const u8 *src = B.in + B.in_off[blk];
         const u32 nin = (u32)(B.in_off[blk + 1] - B.in_off[blk]);

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
         i32 status = ZPQ_OK;
 
         Vm z;
-        z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0;
+        z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0; z.out = nullptr;
         z.m = slot + M.m_off; z.mlen = M.mlen;
         z.h = h_in_lds ? hl : reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
         z.r = reinterpret_cast<u32 *>(slot + M.r_off);

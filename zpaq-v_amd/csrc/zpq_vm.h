@@ -1,15 +1,18 @@
-// zpq_vm.h -- device ZPAQL interpreter shared by zpq_generic.hip and zpq_chain.hip.
+// zpq_vm.h -- ZPAQL interpreter shared by the kernels (HCOMP: contexts per coded byte) and by the
+// host front end (PCOMP: the PostProcessor's PROG mode, decompressor.v:14-167).
 //
 // Reproduces ZPAQL.run / execute and the masked M/H accessors of the reference
 // (zpaq/zpaql.v:167-211,215-954; oplen zpaq/types.v:51-64) including its quirks: operand
 // fetch bounded by header.len (not hend), JT/JF/JMP offset ((N+128)&255)-127 applied after
 // the operand fetch (one more than libzpaq, Q11), undefined opcodes end the run silently
 // (Q12), division/modulo by zero are no-ops, shifts are masked to 5 bits, OUT only grows a
-// host buffer and is ignored here.  The reference has no step budget (a looping program
+// host buffer: it is ignored on the device and appended to Vm::out on the host.  The reference has no step budget (a looping program
 // hangs it); this one stops after ZPQ_VM_STEP_CAP steps and reports it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <vector>
 
 #include "../../include/zpaq_hip.h"
 
@@ -27,15 +30,16 @@ struct Vm {
     u32 *r;
     const u8 *hdr;
     i32 hdr_len, hbegin, hend;
+    void *out;                   // host only: std::vector<uint8_t>* receiving OUT bytes (zpaql.v:151-159); null on the device
 };
 
-__device__ __forceinline__ u32 m_get(const Vm &z, u32 i) { return z.mlen ? z.m[i & (z.mlen - 1)] : 0u; }
-__device__ __forceinline__ void m_set(Vm &z, u32 i, u32 v) { if (z.mlen) z.m[i & (z.mlen - 1)] = (u8)v; }
-__device__ __forceinline__ u32 h_get(const Vm &z, u32 i) { return z.hlen ? z.h[i & (z.hlen - 1)] : 0u; }
-__device__ __forceinline__ void h_set(Vm &z, u32 i, u32 v) { if (z.hlen) z.h[i & (z.hlen - 1)] = v; }
+__host__ __device__ __forceinline__ u32 m_get(const Vm &z, u32 i) { return z.mlen ? z.m[i & (z.mlen - 1)] : 0u; }
+__host__ __device__ __forceinline__ void m_set(Vm &z, u32 i, u32 v) { if (z.mlen) z.m[i & (z.mlen - 1)] = (u8)v; }
+__host__ __device__ __forceinline__ u32 h_get(const Vm &z, u32 i) { return z.hlen ? z.h[i & (z.hlen - 1)] : 0u; }
+__host__ __device__ __forceinline__ void h_set(Vm &z, u32 i, u32 v) { if (z.hlen) z.h[i & (z.hlen - 1)] = v; }
 
 // operand columns 0..7 = A B C D *B *C *D N
-__device__ inline u32 vm_src(const Vm &z, int s, u32 operand)
+__host__ __device__ inline u32 vm_src(const Vm &z, int s, u32 operand)
 {
     switch (s) {
     case 0: return z.a;
@@ -48,7 +52,7 @@ __device__ inline u32 vm_src(const Vm &z, int s, u32 operand)
     default: return operand;
     }
 }
-__device__ inline void vm_dst(Vm &z, int t, u32 v)
+__host__ __device__ inline void vm_dst(Vm &z, int t, u32 v)
 {
     switch (t) {
     case 0: z.a = v; break;
@@ -62,7 +66,7 @@ __device__ inline void vm_dst(Vm &z, int t, u32 v)
 }
 
 // zpaql.v:167-175 + 215-954.  Returns false if the step cap was hit.
-__device__ inline bool vm_run(Vm &z, u32 input)
+__host__ __device__ inline bool vm_run(Vm &z, u32 input)
 {
     z.a = input;
     z.pc = z.hbegin;
@@ -95,7 +99,11 @@ __device__ inline bool vm_run(Vm &z, u32 input)
             } else go = false;             // 5,6,13,14,...: undefined, stops the run
         } else if (op < 64) {
             if (op == 56) go = false;                                             // HALT
-            else if (op == 57) { /* OUT only appends to a host buffer (zpaql.v:151-159) */ }
+            else if (op == 57) {                                                  // OUT (zpaql.v:151-159,382-384)
+#if !defined(__HIP_DEVICE_COMPILE__)
+                if (z.out) static_cast<std::vector<uint8_t> *>(z.out)->push_back((uint8_t)(z.a & 255u));
+#endif
+            }
             else if (op == 59) z.a = (z.a + m_get(z, z.b) + 512u) * 773u;         // HASH
             else if (op == 60) h_set(z, z.d, (h_get(z, z.d) + z.a + 512u) * 773u); // HASHD
             else if (op == 63) z.pc += rel;                                       // JMP
