@@ -170,12 +170,20 @@ struct ArchiveFile {
     int status = ZPQ_OK;      // per-file ZPQ_* code
 };
 // run_add (cmd/main.v:283-311): appends one block per file to *archive.  level 0..5.
-int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive);
+// fragment_bytes > 0 (NOT reference behaviour; the reference parses -fragment and ignores it): a file
+// longer than that is cut into blocks of fragment_bytes, so that one big file is thousands of
+// independent blocks instead of one serial one.  The first block carries the file's name and comment,
+// the others an empty name -- libzpaq's convention for "more of the previous file".  Still a valid ZPAQ
+// level-1 stream; the reference's extractor would see the extra blocks as files without a name.
+int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive,
+                size_t fragment_bytes = 0);
 // run_extract / run_list (cmd/main.v:342-380,440-465): every segment of every block, in archive
 // order.  Single-segment modelled blocks are decoded together in one batch; anything else
 // (store mode, several segments per block) goes through Decompresser.  want_data = false keeps
 // only names, comments and sizes (list).
-int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files);
+// join_unnamed: a segment without a name is appended to the file before it (archives written with fragment_bytes).
+int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files,
+                    bool join_unnamed = false);
 
 }  // namespace zpaq
 
@@ -210,10 +218,12 @@ void zpqf_decompresser_sha1(zpqf_decomp *, uint8_t out20[20]);
 /* archive_add / archive_extract for ctypes: names/comments are NUL-terminated, data[i] has lens[i] bytes.
  * The result lives in the returned handle until zpqf_archive_free. */
 struct zpqf_archive;
+zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
+                                          const uint8_t *const *data, const uint64_t *lens, uint64_t fragment_bytes, int *rc);
 zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
                                const uint8_t *const *data, const uint64_t *lens, int *rc);
 size_t zpqf_archive_bytes(zpqf_archive *, const uint8_t **p);
-zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data, int *rc);
+zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data /* bit 0: data, bit 1: join unnamed */, int *rc);
 int zpqf_archive_nfiles(zpqf_archive *);
 const char *zpqf_archive_name(zpqf_archive *, int i);
 const char *zpqf_archive_comment(zpqf_archive *, int i);

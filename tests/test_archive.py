@@ -271,3 +271,41 @@ def test_postprocessor_mode_byte_corner_cases(zpq, gpu_ctx):
     arc = _prog_archive(zpq, gpu_ctx, 1, "hang", stream, b"")
     got = zpq.archive_extract(gpu_ctx, arc)
     assert got[0]["status"] == -8
+
+
+# ---------------------------------------------------------------- -fragment: one big file = many independent blocks
+def test_fragmented_store_mode_archive_joins_back(zpq):
+    files = [("big", "20000 bytes", bytes(range(256)) * 78 + bytes(32)), ("small", "5 bytes", b"hello"), ("edge", "4096 bytes", bytes(4096))]
+    arc = zpq.archive_add(None, 0, files, fragment_bytes=4096)
+    segs = zpq.archive_extract(None, arc)
+    assert [s["name"] for s in segs] == ["big", "", "", "", "", "small", "edge"]
+    assert [s["size"] for s in segs][:5] == [4096, 4096, 4096, 4096, 20000 - 4 * 4096]
+    joined = zpq.archive_extract(None, arc, join_unnamed=True)
+    assert [(j["name"], j["comment"], j["data"]) for j in joined] == files and all(j["sha1_ok"] for j in joined)
+    assert zpq.archive_add(None, 0, files, fragment_bytes=1 << 20) == zpq.archive_add(None, 0, files)   # nothing to cut
+
+
+@pytest.mark.gpu
+def test_fragmented_archive_on_gpu(zpq, gpu_ctx, tmp_path):
+    big = (INPUTS["text2k"] * 40)[:70001]
+    files = [("a.txt", "70001 bytes", big), ("e", "0 bytes", b""), ("b.bin", "4096 bytes", INPUTS["lcg4k"])]
+    arc = zpq.archive_add(gpu_ctx, 2, files, fragment_bytes=8192)
+    segs = zpq.archive_extract(gpu_ctx, arc)
+    assert len(segs) == 9 + 1 + 1 and all(s["status"] == 0 and s["sha1_ok"] for s in segs)
+    # every fragment is an ordinary block of its own: the same bytes the per-file writer makes for that slice
+    pieces = [("a.txt", "70001 bytes", big[:8192])] + [("", "", big[o:o + 8192]) for o in range(8192, len(big), 8192)] + files[1:]
+    assert arc == oracle_archive(2, pieces)
+    joined = zpq.archive_extract(gpu_ctx, arc, join_unnamed=True)
+    assert [(j["name"], j["data"]) for j in joined] == [(nm, d) for nm, _, d in files]
+    # CLI: -fragment 3 = 8 KiB blocks; list and extract join them again
+    src = tmp_path / "in"
+    src.mkdir()
+    (src / "a.txt").write_bytes(big)
+    a = str(tmp_path / "f.zpaq")
+    r = subprocess.run([CLI, "a", a, str(src / "a.txt"), "-m2", "-fragment", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(a, "rb").read() == oracle_archive(2, pieces[:9])
+    r = subprocess.run([CLI, "l", a], capture_output=True, text=True)
+    assert "a.txt (70001 bytes)" in r.stdout and "Total files: 1" in r.stdout
+    r = subprocess.run([CLI, "x", a, "-to", str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 0 and (tmp_path / "out" / "a.txt").read_bytes() == big

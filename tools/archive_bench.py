@@ -37,3 +37,11 @@ print(json.dumps(dict(workload="%d files x 64 KiB, level %d" % (nb, level), arch
                       list_s=round(t3 - t2, 3), roundtrip_ok=ok,
                       sha1_kernel_ms=round(sha_ms, 3), sha1_kernel_GBps=round(B / sha_ms / 1e6, 1), sha1_ok=ok_sha,
                       host_hashlib_sha1_s=round(host_sha_s, 3))))
+# one big file cut into 64 KiB blocks (-fragment 6): the case the reference's one-block-per-file layout cannot parallelise
+one = [("big.bin", "%d bytes" % B, arr.tobytes())]
+u0 = time.time(); arc1 = z.archive_add(ctx, level, one, fragment_bytes=size); u1 = time.time()
+out1 = z.archive_extract(ctx, arc1, join_unnamed=True); u2 = time.time()
+ok1 = len(out1) == 1 and out1[0]["data"] == one[0][2] and out1[0]["sha1_ok"]
+print(json.dumps(dict(workload="1 file of %d MiB, -fragment 6, level %d" % (B >> 20, level), add_s=round(u1 - u0, 3),
+                      add_MBps=round(B / (u1 - u0) / 1e6, 1), extract_s=round(u2 - u1, 3), extract_MBps=round(B / (u2 - u1) / 1e6, 1),
+                      roundtrip_ok=ok1)))

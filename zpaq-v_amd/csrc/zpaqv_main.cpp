@@ -3,8 +3,9 @@
 // All files of one invocation are coded as ONE GPU batch (zpaq::archive_add / archive_extract);
 // the archive bytes are what the reference's per-file loop writes (one block, one segment per
 // file, basename as segment name, "<n> bytes" as comment; cmd/main.v:283-311).
-// Flags the reference parses but never acts on (-all -index -key -noattributes -repack
-// -threads -until -fragment) are accepted and ignored the same way.
+// Flags the reference parses but never acts on (-all -index -key -noattributes -repack -threads -until)
+// are accepted and ignored the same way.  -fragment N, which the reference also parses and ignores, is
+// given its advertised meaning here as an opt-in: files are cut into 2^N KiB blocks.
 #include <dirent.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +24,7 @@ struct Config {
     std::vector<std::string> files, not_files, only_files, to_files;
     bool force = false, test_mode = false;
     int method = 1, summary = 0;
+    int fragment = -1;            // -fragment N given: cut files into 2^N KiB blocks (the reference parses and ignores it)
 };
 
 bool is_numeric(const std::string &s)
@@ -125,6 +127,9 @@ void print_usage()
     puts("  -sN, -summary N Brief progress.");
     puts("  -test           Extract: verify but do not write files.");
     puts("  -to out...      Extract: use out[0] as output directory prefix.");
+    puts("  -fragment N     Add: cut files into blocks of 2^N KiB (0..20) so that one big file becomes many");
+    puts("                  independent blocks for the GPU.  Not reference behaviour (it ignores the option):");
+    puts("                  without it an archive is byte-identical to the reference CLI's.");
 }
 
 bool parse_args(int argc, char **argv, Config *cfg, std::string *err)
@@ -153,7 +158,8 @@ bool parse_args(int argc, char **argv, Config *cfg, std::string *err)
             else if (name == "noattributes") {}
             else if (name == "m" || name == "method") { if (!need(&cfg->method)) return false; }
             else if (name == "s" || name == "summary") { if (!need(&cfg->summary)) return false; }
-            else if (name == "t" || name == "threads" || name == "all" || name == "until" || name == "fragment") { if (!need(nullptr)) return false; }
+            else if (name == "fragment") { if (!need(&cfg->fragment)) return false; }
+            else if (name == "t" || name == "threads" || name == "all" || name == "until") { if (!need(nullptr)) return false; }
             else if (name == "index" || name == "key" || name == "repack") { if (i + 1 < argc) i++; }
             else if (name == "not") multi = &cfg->not_files;
             else if (name == "only") multi = &cfg->only_files;
@@ -219,7 +225,8 @@ int run_add(const Config &cfg)
         paths.push_back(f);
     }
     zpq_ctx *ctx = cfg.method > 0 ? open_ctx(true) : nullptr;
-    const int rc = zpaq::archive_add(ctx, cfg.method, files, &out);
+    const size_t frag = (cfg.fragment >= 0 && cfg.fragment <= 20) ? ((size_t)1024 << cfg.fragment) : 0;
+    const int rc = zpaq::archive_add(ctx, cfg.method, files, &out, frag);
     if (ctx) zpq_ctx_destroy(ctx);
     if (rc != ZPQ_OK) { fprintf(stderr, "zpaqv: add failed: %s\n", zpq_status_string(rc)); return 1; }
     if (cfg.summary > 0) for (const std::string &p : paths) printf("Added: %s\n", p.c_str());
@@ -236,7 +243,8 @@ int load_and_extract(const Config &cfg, bool want_data, std::vector<zpaq::Archiv
     std::vector<uint8_t> data;
     if (!read_file(*archive, &data)) { fprintf(stderr, "Could not read archive: %s\n", archive->c_str()); return 1; }
     zpq_ctx *ctx = open_ctx(false);
-    const int rc = zpaq::archive_extract(ctx, data.data(), data.size(), want_data, files);
+    // unnamed segments continue the previous file (archives written with -fragment); the reference CLI never writes them
+    const int rc = zpaq::archive_extract(ctx, data.data(), data.size(), want_data, files, true);
     if (ctx) zpq_ctx_destroy(ctx);
     if (rc != ZPQ_OK) { fprintf(stderr, "zpaqv: reading the archive failed: %s\n", zpq_status_string(rc)); return 1; }
     return 0;

@@ -59,21 +59,46 @@ struct VecWriter : Writer {
 }  // namespace
 
 // ------------------------------------------------------------------ add
-int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive)
+namespace {
+// one ZPAQ block to write: a whole file, or one fragment of it (continuations carry no name: libzpaq's
+// convention for "more of the previous file")
+struct Piece {
+    std::string name, comment;
+    const uint8_t *p;
+    size_t n;
+};
+}  // namespace
+
+static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive);
+
+int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive, size_t fragment_bytes)
 {
     if (!archive || level < 0 || level > 5) return ZPQ_E_ARG;
+    std::vector<Piece> pieces;
+    for (const ArchiveFile &f : files) {
+        if (fragment_bytes == 0 || f.data.size() <= fragment_bytes) { pieces.push_back(Piece{f.name, f.comment, f.data.data(), f.data.size()}); continue; }
+        for (size_t off = 0; off < f.data.size(); off += fragment_bytes) {
+            const size_t k = std::min(fragment_bytes, f.data.size() - off);
+            pieces.push_back(off == 0 ? Piece{f.name, f.comment, f.data.data(), k} : Piece{"", "", f.data.data() + off, k});
+        }
+    }
+    return add_pieces(ctx, level, pieces, archive);
+}
+
+static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive)
+{
     VecWriter w(archive);
     const int n = (int)files.size();
     {
         size_t guess = archive->size();
-        for (const ArchiveFile &f : files) guess += f.data.size() / 2 + f.name.size() + f.comment.size() + 128;
+        for (const Piece &f : files) guess += f.n / 2 + f.name.size() + f.comment.size() + 128;
         archive->reserve(guess);
     }
     if (n == 0) return ZPQ_OK;
     if (level == 0) {                                   // store mode has no coder: host only (compressor.v:297-354)
-        for (const ArchiveFile &f : files) {
+        for (const Piece &f : files) {
             Compressor c(nullptr);
-            FileReader r(f.data);
+            FileReader r(std::vector<uint8_t>(f.p, f.p + f.n));
             c.set_output(&w);
             c.start_block(0);
             c.start_segment(f.name, f.comment);
@@ -96,7 +121,7 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
     std::vector<uint64_t> in_off((size_t)n + 1, 0), out_off((size_t)n + 1, 0);
     uint64_t longest = 0;
     for (int i = 0; i < n; i++) {
-        const uint64_t len = files[i].data.size();
+        const uint64_t len = files[i].n;
         if (len > 0xFFFFFF00ull) return ZPQ_E_TOOBIG;
         in_off[i + 1] = in_off[i] + len;
         out_off[i + 1] = out_off[i] + len + len / 4 + 1024;      // overflowing blocks are redone below
@@ -113,8 +138,8 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
         (rc = d_sha.alloc((size_t)n * 20)))
         return rc;
     for (int i = 0; i < n; i++)
-        if (!files[i].data.empty())
-            HK(hipMemcpyAsync(d_in.as<uint8_t>() + in_off[i], files[i].data.data(), files[i].data.size(), hipMemcpyHostToDevice, s));
+        if (files[i].n)
+            HK(hipMemcpyAsync(d_in.as<uint8_t>() + in_off[i], files[i].p, files[i].n, hipMemcpyHostToDevice, s));
     HK(hipMemcpyAsync(d_inoff.p, in_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
     HK(hipMemcpyAsync(d_outoff.p, out_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
     HK(hipMemsetAsync(d_st.p, 0xff, (size_t)n * 4, s));
@@ -149,18 +174,18 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
         if (!coded.empty()) HK(hipMemcpyAsync(coded.data(), d_pk.p, coded.size(), hipMemcpyDeviceToHost, s));
         HK(hipStreamSynchronize(s));
     }
-    if (!gpu_sha) for (int i = 0; i < n; i++) host_sha1(files[i].data.data(), files[i].data.size(), &sha[(size_t)i * 20]);
+    if (!gpu_sha) for (int i = 0; i < n; i++) host_sha1(files[i].p, files[i].n, &sha[(size_t)i * 20]);
 
     // a payload that outgrew its slab (possible: worst case ~16x) is coded again alone
     std::map<int, std::vector<uint8_t>> redo;
     for (int i = 0; i < n; i++) {
         if (st[i] == ZPQ_OK) continue;
         if (st[i] != ZPQ_E_OVERFLOW) return st[i];
-        std::vector<uint8_t> big(files[i].data.size() * 17 + 4096);
-        const uint64_t io[2] = {0, files[i].data.size()}, oo[2] = {0, big.size()};
+        std::vector<uint8_t> big(files[i].n * 17 + 4096);
+        const uint64_t io[2] = {0, files[i].n}, oo[2] = {0, big.size()};
         uint32_t bl = 0;
         int32_t bs = 0;
-        if ((rc = zpq_encode_blocks(ctx, model, 1, files[i].data.data(), io, ZPQ_FLAG_PP, big.data(), oo, &bl, &bs)) != ZPQ_OK) return rc;
+        if ((rc = zpq_encode_blocks(ctx, model, 1, files[i].p, io, ZPQ_FLAG_PP, big.data(), oo, &bl, &bs)) != ZPQ_OK) return rc;
         if (bs != ZPQ_OK) return bs;
         big.resize(bl);
         redo[i] = std::move(big);
@@ -289,9 +314,28 @@ uint64_t size_hint(const std::string &comment)            // the CLI's "<n> byte
 
 }  // namespace
 
-int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
+static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files);
+
+int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files, bool join_unnamed)
 {
     if (!files || (n && !arc)) return ZPQ_E_ARG;
+    if (!join_unnamed) return extract_segments(ctx, arc, n, want_data, files);
+    std::vector<ArchiveFile> segs;
+    const int rc = extract_segments(ctx, arc, n, want_data, &segs);
+    for (ArchiveFile &sg : segs) {
+        if (sg.name.empty() && !files->empty()) {              // a fragment: more of the previous file
+            ArchiveFile &f = files->back();
+            f.size += sg.size;
+            f.sha1_ok = f.sha1_ok && sg.sha1_ok;
+            if (f.status == ZPQ_OK) f.status = sg.status;
+            f.data.insert(f.data.end(), sg.data.begin(), sg.data.end());
+        } else files->push_back(std::move(sg));
+    }
+    return rc;
+}
+
+static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
+{
     // ---- pass 1: every block the sequential loop would visit
     std::vector<BlockRec> blocks;
     {
@@ -334,7 +378,10 @@ int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, 
                     const BlockRec &b = blocks[(size_t)todo[k]];
                     const uint64_t hint = size_hint(b.comment);
                     const uint64_t paylen = b.next_tag - b.payload;
-                    uint64_t cap = (hint != ~0ull && attempt == 0) ? hint + 64 : paylen * 8 + 65536;
+                    // first try: the size the comment promises, but never absurdly more than the payload could
+                    // plausibly expand to (the first fragment of a split file carries the WHOLE file's size)
+                    uint64_t cap = paylen * 8 + 65536;
+                    if (hint != ~0ull && attempt == 0) cap = std::min<uint64_t>(hint + 64, paylen * 4096 + 65536);
                     cap *= capmul[(size_t)todo[k]];
                     cap = std::min<uint64_t>(cap, 0xFFFFFF00ull);
                     out_off[k + 1] = out_off[k] + ((cap + 15) & ~15ull);
@@ -373,11 +420,23 @@ int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, 
                     HK(hipMemcpyAsync(sha.data(), d_sha.p, (size_t)m * 20, hipMemcpyDeviceToHost, s));
                     HK(hipStreamSynchronize(s));
                 }
+                // decoded blocks sit in capacity-strided slabs: pack them on the device, download only real bytes
+                std::vector<uint64_t> pk_off((size_t)m + 1, 0);
+                for (int k = 0; k < m; k++) pk_off[k + 1] = pk_off[k] + (st[k] == ZPQ_OK ? len[k] : 0);
                 if (want_data || !gpu_sha) {
-                    slab.resize((size_t)out_off[m]);
-                    HK(hipMemcpyAsync(slab.data(), d_out.p, slab.size(), hipMemcpyDeviceToHost, s));
+                    std::vector<uint32_t> plen((size_t)m);
+                    for (int k = 0; k < m; k++) plen[k] = st[k] == ZPQ_OK ? len[k] : 0;
+                    DevMem d_pk, d_pkoff, d_plen;
+                    if ((rc = d_pk.alloc(pk_off[m] + 64)) || (rc = d_pkoff.alloc(((size_t)m + 1) * 8)) || (rc = d_plen.alloc(u))) return rc;
+                    HK(hipMemcpyAsync(d_pkoff.p, pk_off.data(), ((size_t)m + 1) * 8, hipMemcpyHostToDevice, s));
+                    HK(hipMemcpyAsync(d_plen.p, plen.data(), u, hipMemcpyHostToDevice, s));
+                    if ((rc = zpq_gather_dev(ctx, m, d_out.as<uint8_t>(), d_outoff.as<uint64_t>(), d_plen.as<uint32_t>(), d_pk.as<uint8_t>(),
+                                             d_pkoff.as<uint64_t>())) != ZPQ_OK)
+                        return rc;
+                    slab.resize((size_t)pk_off[m]);
+                    if (!slab.empty()) HK(hipMemcpyAsync(slab.data(), d_pk.p, slab.size(), hipMemcpyDeviceToHost, s));
                     HK(hipStreamSynchronize(s));
-                    if (!gpu_sha) for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) host_sha1(slab.data() + out_off[k], len[k], &sha[(size_t)k * 20]);
+                    if (!gpu_sha) for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) host_sha1(slab.data() + pk_off[k], len[k], &sha[(size_t)k * 20]);
                 }
                 // ---- pass 3: trailer walk per block (Decoder.skip decoder.v:151-196, read_segment_end decompressor.v:590-635)
                 std::vector<int> again;
@@ -407,7 +466,7 @@ int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, 
                     d.f.comment = b.comment;
                     d.f.sha1_ok = sha_ok;
                     d.f.size = first[k] == 0xFFFFFFFFu ? 0 : len[k];
-                    if (want_data && d.f.size) d.f.data.assign(slab.begin() + (ptrdiff_t)out_off[k], slab.begin() + (ptrdiff_t)(out_off[k] + len[k]));
+                    if (want_data && d.f.size) d.f.data.assign(slab.begin() + (ptrdiff_t)pk_off[k], slab.begin() + (ptrdiff_t)(pk_off[k] + len[k]));
                 }
                 todo.swap(again);
             }
@@ -430,8 +489,8 @@ struct zpqf_archive {
 };
 
 extern "C" {
-zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
-                               const uint8_t *const *data, const uint64_t *lens, int *rc)
+zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
+                                          const uint8_t *const *data, const uint64_t *lens, uint64_t fragment_bytes, int *rc)
 {
     zpqf_archive *h = new zpqf_archive();
     std::vector<zpaq::ArchiveFile> files((size_t)(nfiles > 0 ? nfiles : 0));
@@ -440,15 +499,20 @@ zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *
         files[(size_t)i].comment = comments[i];
         files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
     }
-    const int r = zpaq::archive_add(ctx, level, files, &h->bytes);
+    const int r = zpaq::archive_add(ctx, level, files, &h->bytes, (size_t)fragment_bytes);
     if (rc) *rc = r;
     return h;
+}
+zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
+                               const uint8_t *const *data, const uint64_t *lens, int *rc)
+{
+    return zpqf_archive_add_fragmented(ctx, level, nfiles, names, comments, data, lens, 0, rc);
 }
 size_t zpqf_archive_bytes(zpqf_archive *h, const uint8_t **p) { *p = h->bytes.data(); return h->bytes.size(); }
 zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data, int *rc)
 {
     zpqf_archive *h = new zpqf_archive();
-    const int r = zpaq::archive_extract(ctx, arc, n, want_data != 0, &h->files);
+    const int r = zpaq::archive_extract(ctx, arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
     if (rc) *rc = r;
     return h;
 }

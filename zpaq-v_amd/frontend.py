@@ -44,6 +44,8 @@ def _lib():
     L.zpqf_decompresser_sha1.argtypes = [vp, vp]
     L.zpqf_archive_add.restype = vp
     L.zpqf_archive_add.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.zpqf_archive_add_fragmented.restype = vp
+    L.zpqf_archive_add_fragmented.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
     L.zpqf_archive_bytes.restype = C.c_size_t
     L.zpqf_archive_bytes.argtypes = [vp, vp]
     L.zpqf_archive_extract.restype = vp
@@ -167,9 +169,10 @@ class Decompresser:
         return out.raw
 
 
-def archive_add(ctx, level, files):
+def archive_add(ctx, level, files, fragment_bytes=0):
     """zpaq::archive_add: the reference CLI's add loop (cmd/main.v:283-311) for a list of
-    (name, comment, data) as ONE GPU batch.  Returns the archive bytes."""
+    (name, comment, data) as ONE GPU batch.  Returns the archive bytes.  fragment_bytes > 0 cuts
+    longer files into blocks of that size (continuation blocks carry an empty name)."""
     L = _lib()
     n = len(files)
     names = (C.c_char_p * n)(*[f[0].encode() for f in files])
@@ -178,7 +181,8 @@ def archive_add(ctx, level, files):
     data = (C.c_char_p * n)(*keep)
     lens = (C.c_uint64 * n)(*[len(k) for k in keep])
     rc = C.c_int(0)
-    h = L.zpqf_archive_add(ctx.h if ctx is not None else None, level, n, names, comments, data, lens, C.byref(rc))
+    h = L.zpqf_archive_add_fragmented(ctx.h if ctx is not None else None, level, n, names, comments, data, lens,
+                                      fragment_bytes, C.byref(rc))
     try:
         if rc.value != 0:
             raise B.ZpqError(rc.value, "archive_add")
@@ -189,13 +193,14 @@ def archive_add(ctx, level, files):
         L.zpqf_archive_free(h)
 
 
-def archive_extract(ctx, archive, want_data=True):
+def archive_extract(ctx, archive, want_data=True, join_unnamed=False):
     """zpaq::archive_extract: every segment of every block in archive order
     (cmd/main.v:342-380,440-465).  Returns dicts name/comment/size/sha1_ok/status/data."""
     L = _lib()
     archive = bytes(archive)
     rc = C.c_int(0)
-    h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive), 1 if want_data else 0, C.byref(rc))
+    h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive),
+                               (1 if want_data else 0) | (2 if join_unnamed else 0), C.byref(rc))
     try:
         if rc.value != 0:
             raise B.ZpqError(rc.value, "archive_extract")
