@@ -181,8 +181,14 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
 // order.  Single-segment modelled blocks are decoded together in one batch; anything else
 // (store mode, several segments per block) goes through Decompresser.  want_data = false keeps
 // only names, comments and sizes (list).
+// Several GPUs: block b -> ctxs[b mod G], one host thread per context, no collective; results are in
+// archive order and identical for any G (ctxs[0] also serves the sequential replay path).
+int archive_add(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive,
+                size_t fragment_bytes = 0);
 // join_unnamed: a segment without a name is appended to the file before it (archives written with fragment_bytes).
 int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files,
+                    bool join_unnamed = false);
+int archive_extract(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files,
                     bool join_unnamed = false);
 
 }  // namespace zpaq
@@ -222,6 +228,11 @@ zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, c
                                           const uint8_t *const *data, const uint64_t *lens, uint64_t fragment_bytes, int *rc);
 zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
                                const uint8_t *const *data, const uint64_t *lens, int *rc);
+/* several GPUs: block b -> ctxs[b mod nctx] */
+zpqf_archive *zpqf_archive_add_multi(zpq_ctx *const *ctxs, int nctx, int level, int nfiles, const char *const *names,
+                                     const char *const *comments, const uint8_t *const *data, const uint64_t *lens,
+                                     uint64_t fragment_bytes, int *rc);
+zpqf_archive *zpqf_archive_extract_multi(zpq_ctx *const *ctxs, int nctx, const uint8_t *arc, size_t n, int want_data, int *rc);
 size_t zpqf_archive_bytes(zpqf_archive *, const uint8_t **p);
 zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data /* bit 0: data, bit 1: join unnamed */, int *rc);
 int zpqf_archive_nfiles(zpqf_archive *);

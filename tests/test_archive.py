@@ -309,3 +309,22 @@ def test_fragmented_archive_on_gpu(zpq, gpu_ctx, tmp_path):
     assert "a.txt (70001 bytes)" in r.stdout and "Total files: 1" in r.stdout
     r = subprocess.run([CLI, "x", a, "-to", str(tmp_path / "out")], capture_output=True, text=True)
     assert r.returncode == 0 and (tmp_path / "out" / "a.txt").read_bytes() == big
+
+
+@pytest.mark.gpu
+def test_sharded_over_two_contexts_is_position_stable(zpq, gpu_ctx):
+    """Several GPUs: block b -> context b mod G, a host thread per context, no collective.  Rehearsed with two
+    contexts on the one GPU of this box: the archive and the extracted files must not depend on G."""
+    other = zpq.Context(0)
+    try:
+        files = file_set(seed=21, n=30) + [("big", "50000 bytes", (INPUTS["text2k"] * 30)[:50000])]
+        one = zpq.archive_add(gpu_ctx, 2, files, fragment_bytes=8192)
+        two = zpq.archive_add([gpu_ctx, other], 2, files, fragment_bytes=8192)
+        assert one == two
+        a = zpq.archive_extract(gpu_ctx, one, join_unnamed=True)
+        b = zpq.archive_extract([gpu_ctx, other], one, join_unnamed=True)
+        assert a == b and [(x["name"], x["data"]) for x in b] == [(nm, d) for nm, _, d in files]
+        mixed = zpq.archive_add(None, 0, files[:3]) + one               # store-mode blocks go through the replay path
+        assert [x["name"] for x in zpq.archive_extract([gpu_ctx, other], mixed, join_unnamed=True)] == [f[0] for f in files[:3] + files]
+    finally:
+        other.close()

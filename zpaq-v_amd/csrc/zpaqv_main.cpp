@@ -24,6 +24,7 @@ struct Config {
     std::vector<std::string> files, not_files, only_files, to_files;
     bool force = false, test_mode = false;
     int method = 1, summary = 0;
+    int threads = 1;              // -tN / -threads N: GPUs to spread the blocks over (0 = all visible); the reference ignores it
     int fragment = -1;            // -fragment N given: cut files into 2^N KiB blocks (the reference parses and ignores it)
 };
 
@@ -127,6 +128,7 @@ void print_usage()
     puts("  -sN, -summary N Brief progress.");
     puts("  -test           Extract: verify but do not write files.");
     puts("  -to out...      Extract: use out[0] as output directory prefix.");
+    puts("  -tN, -threads N Spread the blocks over N GPUs (block b -> GPU b mod N; 0 = all; default 1).");
     puts("  -fragment N     Add: cut files into blocks of 2^N KiB (0..20) so that one big file becomes many");
     puts("                  independent blocks for the GPU.  Not reference behaviour (it ignores the option):");
     puts("                  without it an archive is byte-identical to the reference CLI's.");
@@ -144,7 +146,7 @@ bool parse_args(int argc, char **argv, Config *cfg, std::string *err)
             // zpaq-style -mN -sN -tN (cmd/main.v:165-194)
             if (name.size() >= 2 && (name[0] == 'm' || name[0] == 's' || name[0] == 't') && is_numeric(name.substr(1))) {
                 const int v = atoi(name.c_str() + 1);
-                if (name[0] == 'm') cfg->method = v; else if (name[0] == 's') cfg->summary = v;
+                if (name[0] == 'm') cfg->method = v; else if (name[0] == 's') cfg->summary = v; else cfg->threads = v;
                 continue;
             }
             auto need = [&](int *dst) -> bool {
@@ -159,7 +161,8 @@ bool parse_args(int argc, char **argv, Config *cfg, std::string *err)
             else if (name == "m" || name == "method") { if (!need(&cfg->method)) return false; }
             else if (name == "s" || name == "summary") { if (!need(&cfg->summary)) return false; }
             else if (name == "fragment") { if (!need(&cfg->fragment)) return false; }
-            else if (name == "t" || name == "threads" || name == "all" || name == "until") { if (!need(nullptr)) return false; }
+            else if (name == "t" || name == "threads") { if (!need(&cfg->threads)) return false; }
+            else if (name == "all" || name == "until") { if (!need(nullptr)) return false; }
             else if (name == "index" || name == "key" || name == "repack") { if (i + 1 < argc) i++; }
             else if (name == "not") multi = &cfg->not_files;
             else if (name == "only") multi = &cfg->only_files;
@@ -190,14 +193,27 @@ std::string archive_name(const Config &cfg)
     return (a.size() >= 5 && a.compare(a.size() - 5, 5, ".zpaq") == 0) ? a : a + ".zpaq";
 }
 
-zpq_ctx *open_ctx(bool required)
+// one context per GPU: devices ZPAQV_DEVICE, +1, ... (-tN; 0 = as many as there are).  {nullptr} if none works.
+std::vector<zpq_ctx *> open_ctxs(const Config &cfg, bool required)
 {
-    zpq_ctx *ctx = nullptr;
+    std::vector<zpq_ctx *> ctxs;
     const char *dev = getenv("ZPAQV_DEVICE");
-    const int rc = zpq_ctx_create(dev ? atoi(dev) : 0, &ctx);
-    if (rc != ZPQ_OK && required) fprintf(stderr, "zpaqv: no usable MI355X device (%s); only -m0 archives can be handled\n", zpq_status_string(rc));
-    return rc == ZPQ_OK ? ctx : nullptr;
+    const int first = dev ? atoi(dev) : 0;
+    const int want = cfg.threads > 0 ? cfg.threads : 64;
+    int rc = ZPQ_OK;
+    for (int i = 0; i < want; i++) {
+        zpq_ctx *c = nullptr;
+        rc = zpq_ctx_create(first + i, &c);
+        if (rc != ZPQ_OK) break;
+        ctxs.push_back(c);
+    }
+    if (ctxs.empty()) {
+        if (required) fprintf(stderr, "zpaqv: no usable MI355X device (%s); only -m0 archives can be handled\n", zpq_status_string(rc));
+        ctxs.push_back(nullptr);
+    }
+    return ctxs;
 }
+void close_ctxs(std::vector<zpq_ctx *> &ctxs) { for (zpq_ctx *c : ctxs) if (c) zpq_ctx_destroy(c); ctxs.clear(); }
 
 // cmd/main.v:239-327
 int run_add(const Config &cfg)
@@ -224,10 +240,10 @@ int run_add(const Config &cfg)
         files.push_back(std::move(af));
         paths.push_back(f);
     }
-    zpq_ctx *ctx = cfg.method > 0 ? open_ctx(true) : nullptr;
+    std::vector<zpq_ctx *> ctxs = cfg.method > 0 ? open_ctxs(cfg, true) : std::vector<zpq_ctx *>{nullptr};
     const size_t frag = (cfg.fragment >= 0 && cfg.fragment <= 20) ? ((size_t)1024 << cfg.fragment) : 0;
-    const int rc = zpaq::archive_add(ctx, cfg.method, files, &out, frag);
-    if (ctx) zpq_ctx_destroy(ctx);
+    const int rc = zpaq::archive_add(ctxs, cfg.method, files, &out, frag);
+    close_ctxs(ctxs);
     if (rc != ZPQ_OK) { fprintf(stderr, "zpaqv: add failed: %s\n", zpq_status_string(rc)); return 1; }
     if (cfg.summary > 0) for (const std::string &p : paths) printf("Added: %s\n", p.c_str());
     if (!write_file(archive, out.data(), out.size())) { fprintf(stderr, "Could not write archive: %s\n", archive.c_str()); return 1; }
@@ -242,10 +258,10 @@ int load_and_extract(const Config &cfg, bool want_data, std::vector<zpaq::Archiv
     if (!exists(*archive)) { fprintf(stderr, "Archive '%s' not found\n", archive->c_str()); return 1; }
     std::vector<uint8_t> data;
     if (!read_file(*archive, &data)) { fprintf(stderr, "Could not read archive: %s\n", archive->c_str()); return 1; }
-    zpq_ctx *ctx = open_ctx(false);
+    std::vector<zpq_ctx *> ctxs = open_ctxs(cfg, false);
     // unnamed segments continue the previous file (archives written with -fragment); the reference CLI never writes them
-    const int rc = zpaq::archive_extract(ctx, data.data(), data.size(), want_data, files, true);
-    if (ctx) zpq_ctx_destroy(ctx);
+    const int rc = zpaq::archive_extract(ctxs, data.data(), data.size(), want_data, files, true);
+    close_ctxs(ctxs);
     if (rc != ZPQ_OK) { fprintf(stderr, "zpaqv: reading the archive failed: %s\n", zpq_status_string(rc)); return 1; }
     return 0;
 }

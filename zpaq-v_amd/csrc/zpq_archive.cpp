@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <map>
+#include <thread>
 
 #include "../../include/zpaq_frontend.hpp"
 
@@ -69,11 +70,19 @@ struct Piece {
 };
 }  // namespace
 
-static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive);
+static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive, std::vector<size_t> *ends);
 
 int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive, size_t fragment_bytes)
 {
-    if (!archive || level < 0 || level > 5) return ZPQ_E_ARG;
+    return archive_add(std::vector<zpq_ctx *>{ctx}, level, files, archive, fragment_bytes);
+}
+
+// Several GPUs: block b -> context b mod G, one host thread per context, no collective; the
+// blocks are written out in their original order, so the archive does not depend on G.
+int archive_add(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive,
+                size_t fragment_bytes)
+{
+    if (!archive || level < 0 || level > 5 || ctxs.empty()) return ZPQ_E_ARG;
     std::vector<Piece> pieces;
     for (const ArchiveFile &f : files) {
         if (fragment_bytes == 0 || f.data.size() <= fragment_bytes) { pieces.push_back(Piece{f.name, f.comment, f.data.data(), f.data.size()}); continue; }
@@ -82,10 +91,27 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
             pieces.push_back(off == 0 ? Piece{f.name, f.comment, f.data.data(), k} : Piece{"", "", f.data.data() + off, k});
         }
     }
-    return add_pieces(ctx, level, pieces, archive);
+    const size_t G = (level == 0 || pieces.size() < 2) ? 1 : std::min(ctxs.size(), pieces.size());
+    if (G <= 1) return add_pieces(ctxs[0], level, pieces, archive, nullptr);
+    std::vector<std::vector<Piece>> shard(G);
+    for (size_t i = 0; i < pieces.size(); i++) shard[i % G].push_back(pieces[i]);
+    std::vector<std::vector<uint8_t>> outs(G);
+    std::vector<std::vector<size_t>> ends(G);
+    std::vector<int> rcs(G, ZPQ_OK);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++)
+        th.emplace_back([&, g]() { rcs[g] = add_pieces(ctxs[g], level, shard[g], &outs[g], &ends[g]); });
+    for (std::thread &t : th) t.join();
+    for (int r : rcs) if (r != ZPQ_OK) return r;
+    for (size_t i = 0; i < pieces.size(); i++) {
+        const size_t g = i % G, k = i / G;
+        const size_t from = k ? ends[g][k - 1] : 0;
+        archive->insert(archive->end(), outs[g].begin() + (ptrdiff_t)from, outs[g].begin() + (ptrdiff_t)ends[g][k]);
+    }
+    return ZPQ_OK;
 }
 
-static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive)
+static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, std::vector<uint8_t> *archive, std::vector<size_t> *ends)
 {
     VecWriter w(archive);
     const int n = (int)files.size();
@@ -106,6 +132,7 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
             while (c.compress(65536)) {}
             c.end_segment();
             c.end_block();
+            if (ends) ends->push_back(archive->size());
         }
         return ZPQ_OK;
     }
@@ -198,6 +225,7 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
         else w.write(coded.data() + pk_off[i], (int)lens[i]);
         framing::segment_trailer(w, &sha[(size_t)i * 20]);
         framing::block_end(w);
+        if (ends) ends->push_back(archive->size());
     }
     return ZPQ_OK;
 }
@@ -314,14 +342,20 @@ uint64_t size_hint(const std::string &comment)            // the CLI's "<n> byte
 
 }  // namespace
 
-static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files);
+static int extract_segments(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files);
 
 int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files, bool join_unnamed)
 {
-    if (!files || (n && !arc)) return ZPQ_E_ARG;
-    if (!join_unnamed) return extract_segments(ctx, arc, n, want_data, files);
+    return archive_extract(std::vector<zpq_ctx *>{ctx}, arc, n, want_data, files, join_unnamed);
+}
+
+int archive_extract(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files,
+                    bool join_unnamed)
+{
+    if (!files || (n && !arc) || ctxs.empty()) return ZPQ_E_ARG;
+    if (!join_unnamed) return extract_segments(ctxs, arc, n, want_data, files);
     std::vector<ArchiveFile> segs;
-    const int rc = extract_segments(ctx, arc, n, want_data, &segs);
+    const int rc = extract_segments(ctxs, arc, n, want_data, &segs);
     for (ArchiveFile &sg : segs) {
         if (sg.name.empty() && !files->empty()) {              // a fragment: more of the previous file
             ArchiveFile &f = files->back();
@@ -334,8 +368,16 @@ int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, 
     return rc;
 }
 
-static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
+namespace {
+struct Decoded { bool done = false; ArchiveFile f; };
+typedef std::map<std::vector<uint8_t>, std::vector<int>> Groups;
+}  // namespace
+static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, const std::vector<BlockRec> &blocks,
+                         const Groups &groups, std::vector<Decoded> &dec);
+
+static int extract_segments(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
 {
+    zpq_ctx *ctx = ctxs[0];
     // ---- pass 1: every block the sequential loop would visit
     std::vector<BlockRec> blocks;
     {
@@ -348,19 +390,46 @@ static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool wan
         for (size_t i = 0; i < blocks.size(); i++) blocks[i].next_tag = i + 1 < blocks.size() ? blocks[i + 1].tag_pos : n;
     }
     // ---- pass 2: one batch per distinct header over the single-segment candidates
-    struct Decoded { bool done = false; ArchiveFile f; };
     std::vector<Decoded> dec(blocks.size());
-    std::map<std::vector<uint8_t>, std::vector<int>> groups;
+    // candidates dealt round-robin over the contexts (block b -> context b mod G), one host thread each
+    size_t G = 0;
+    for (zpq_ctx *c : ctxs) if (c) G++; else break;
+    std::vector<Groups> groups(G ? G : 1);
+    size_t ncand = 0;
     for (size_t i = 0; i < blocks.size(); i++)
-        if (blocks[i].ncomp > 0 && blocks[i].has_segment && ctx && n < 0xFFFFFF00ull) groups[blocks[i].hdr].push_back((int)i);
-    if (!groups.empty()) {
+        if (blocks[i].ncomp > 0 && blocks[i].has_segment && G && n < 0xFFFFFF00ull) groups[ncand++ % G][blocks[i].hdr].push_back((int)i);
+    if (ncand) {
+        std::vector<int> rcs(G, ZPQ_OK);
+        if (G == 1 || ncand < 2) rcs[0] = decode_groups(ctxs[0], arc, n, want_data, blocks, groups[0], dec);
+        else {
+            std::vector<std::thread> th;
+            for (size_t g = 0; g < G; g++)
+                th.emplace_back([&, g]() { rcs[g] = decode_groups(ctxs[g], arc, n, want_data, blocks, groups[g], dec); });
+            for (std::thread &t : th) t.join();
+        }
+        for (int r : rcs) if (r != ZPQ_OK) return r;
+    }
+    // ---- everything else, in archive order
+    for (size_t i = 0; i < blocks.size(); i++) {
+        if (dec[i].done) { files->push_back(std::move(dec[i].f)); continue; }
+        replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
+    }
+    return ZPQ_OK;
+}
+
+// one context's share: a batch per distinct header (writes only the dec[] entries of its own blocks)
+static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, const std::vector<BlockRec> &blocks,
+                         const Groups &groups, std::vector<Decoded> &dec)
+{
+    if (groups.empty()) return ZPQ_OK;
+    {
         HK(hipSetDevice(zpq_ctx_device(ctx)));
         hipStream_t s = (hipStream_t)zpq_ctx_stream(ctx);
         DevMem d_arc;
         int rc;
         if ((rc = d_arc.alloc(n + 64))) return rc;
         HK(hipMemcpyAsync(d_arc.p, arc, n, hipMemcpyHostToDevice, s));
-        for (auto &g : groups) {
+        for (const auto &g : groups) {
             const BlockRec &b0 = blocks[(size_t)g.second[0]];
             zpq_model *model = nullptr;
             if (zpq_model_create(b0.hdr.data(), (int)b0.hdr.size(), b0.cend, b0.hbegin, b0.hend, &model) != ZPQ_OK) continue;   // replayed below
@@ -472,11 +541,6 @@ static int extract_segments(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool wan
             }
         }
     }
-    // ---- everything else, in archive order
-    for (size_t i = 0; i < blocks.size(); i++) {
-        if (dec[i].done) { files->push_back(std::move(dec[i].f)); continue; }
-        replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
-    }
     return ZPQ_OK;
 }
 
@@ -500,6 +564,28 @@ zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, c
         files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
     }
     const int r = zpaq::archive_add(ctx, level, files, &h->bytes, (size_t)fragment_bytes);
+    if (rc) *rc = r;
+    return h;
+}
+zpqf_archive *zpqf_archive_add_multi(zpq_ctx *const *ctxs, int nctx, int level, int nfiles, const char *const *names,
+                                     const char *const *comments, const uint8_t *const *data, const uint64_t *lens,
+                                     uint64_t fragment_bytes, int *rc)
+{
+    zpqf_archive *h = new zpqf_archive();
+    std::vector<zpaq::ArchiveFile> files((size_t)(nfiles > 0 ? nfiles : 0));
+    for (int i = 0; i < nfiles; i++) {
+        files[(size_t)i].name = names[i];
+        files[(size_t)i].comment = comments[i];
+        files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
+    }
+    const int r = zpaq::archive_add(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), level, files, &h->bytes, (size_t)fragment_bytes);
+    if (rc) *rc = r;
+    return h;
+}
+zpqf_archive *zpqf_archive_extract_multi(zpq_ctx *const *ctxs, int nctx, const uint8_t *arc, size_t n, int want_data, int *rc)
+{
+    zpqf_archive *h = new zpqf_archive();
+    const int r = zpaq::archive_extract(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
     if (rc) *rc = r;
     return h;
 }

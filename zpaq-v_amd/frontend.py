@@ -46,6 +46,10 @@ def _lib():
     L.zpqf_archive_add.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.zpqf_archive_add_fragmented.restype = vp
     L.zpqf_archive_add_fragmented.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
+    L.zpqf_archive_add_multi.restype = vp
+    L.zpqf_archive_add_multi.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_uint64, vp]
+    L.zpqf_archive_extract_multi.restype = vp
+    L.zpqf_archive_extract_multi.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_int, vp]
     L.zpqf_archive_bytes.restype = C.c_size_t
     L.zpqf_archive_bytes.argtypes = [vp, vp]
     L.zpqf_archive_extract.restype = vp
@@ -181,8 +185,12 @@ def archive_add(ctx, level, files, fragment_bytes=0):
     data = (C.c_char_p * n)(*keep)
     lens = (C.c_uint64 * n)(*[len(k) for k in keep])
     rc = C.c_int(0)
-    h = L.zpqf_archive_add_fragmented(ctx.h if ctx is not None else None, level, n, names, comments, data, lens,
-                                      fragment_bytes, C.byref(rc))
+    if isinstance(ctx, (list, tuple)):                       # several GPUs: block b -> ctx[b mod G]
+        arr = (C.c_void_p * len(ctx))(*[c.h for c in ctx])
+        h = L.zpqf_archive_add_multi(arr, len(ctx), level, n, names, comments, data, lens, fragment_bytes, C.byref(rc))
+    else:
+        h = L.zpqf_archive_add_fragmented(ctx.h if ctx is not None else None, level, n, names, comments, data, lens,
+                                          fragment_bytes, C.byref(rc))
     try:
         if rc.value != 0:
             raise B.ZpqError(rc.value, "archive_add")
@@ -199,8 +207,12 @@ def archive_extract(ctx, archive, want_data=True, join_unnamed=False):
     L = _lib()
     archive = bytes(archive)
     rc = C.c_int(0)
-    h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive),
-                               (1 if want_data else 0) | (2 if join_unnamed else 0), C.byref(rc))
+    mode = (1 if want_data else 0) | (2 if join_unnamed else 0)
+    if isinstance(ctx, (list, tuple)):
+        arr = (C.c_void_p * len(ctx))(*[c.h for c in ctx])
+        h = L.zpqf_archive_extract_multi(arr, len(ctx), archive, len(archive), mode, C.byref(rc))
+    else:
+        h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive), mode, C.byref(rc))
     try:
         if rc.value != 0:
             raise B.ZpqError(rc.value, "archive_extract")
