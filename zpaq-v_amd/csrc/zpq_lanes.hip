@@ -318,16 +318,19 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
                 // reference reads last bit's value there (predictor.v:536-668 walks i = 0..n-1 over one
                 // persistent p[]), so every lane keeps its previous prediction in pprev.
                 const i32 pprev = pown;
-                if (type == ZT_CONST) pown = (ca - 128) * 16;
-                else if (type == ZT_CM) pown = stretch((i32)(v0 >> 17));
-                else if (type == ZT_ICM) pown = stretch((i32)(v0 >> 8));
-                else if (type == ZT_MATCH) {
-                    if (ma == 0) pown = 0;
-                    else {
-                        mc = (i32)((v0 >> (7u - mcxt)) & 1u);
-                        pown = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
-                    }
-                } else if (type == ZT_NONE || type > ZT_SSE) pown = 0;
+                {
+                    // CONST / CM / ICM / MATCH / leftovers resolve together: one stretch() for all lanes instead of
+                    // one per type branch (predictor.v:546-574)
+                    const bool t_cm = type == ZT_CM, t_icm = type == ZT_ICM, t_match = type == ZT_MATCH;
+                    const bool live_match = t_match && ma != 0;
+                    mc = live_match ? (i32)((v0 >> (7u - mcxt)) & 1u) : mc;
+                    const i32 mterm = (s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767;
+                    const i32 sin = t_cm ? (i32)(v0 >> 17) : (t_icm ? (i32)(v0 >> 8) : mterm);
+                    const i32 stv = stretch(sin);
+                    const i32 val = (t_cm || t_icm || live_match) ? stv : (type == ZT_CONST ? (ca - 128) * 16 : 0);
+                    const bool indep = type <= ZT_MATCH || type > ZT_SSE;          // NONE(0), CONST, CM, ICM, MATCH, unknown
+                    pown = indep ? val : pown;
+                }
                 i32 pin0 = 0, pin1 = 0;
                 for (u64 dm = cfg.depmask; dm != 0; dm &= dm - 1) {
                     const int ci = __builtin_ctzll(dm);
@@ -418,6 +421,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
                 LPROF(3);
                 // ================= D. every lane trains its component =================
                 const i32 t32767 = y ? 32767 : 0;
+                if (hashed) myrow[slotn] = s_ns[st * 4 + y];     // next bit-history state (predictor.v:704,790)
                 // training reads the finished predictions of this bit (predictor.v:672-824 runs after predict)
                 const i32 fin_b = cfg.has_isse ? __shfl(pown, cb & 63) : 0;
                 const i32 fin_j = cfg.has_mix2 ? __shfl(pown, cj & 63) : 0;
@@ -428,8 +432,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
                     const i32 err = t32767 - (i32)(v0 >> 17);
                     const i32 upd = wmul(err, (i32)s_dt[count]) & -1024;
                     cm[idx] = (u32)wadd(wadd((i32)v0, upd), count < climit ? 1 : 0);
-                } else if (type == ZT_ICM) {                       // predictor.v:701-709
-                    myrow[slotn] = s_ns[st * 4 + y];
+                } else if (type == ZT_ICM) {                       // predictor.v:701-709 (row state: below, with ISSE)
                     cm[st] = (u32)wadd((i32)v0, (t32767 - (i32)(v0 >> 8)) >> 2);
                 } else if (type == ZT_ISSE) {                      // predictor.v:776-791
                     const i32 err = t32767 - sqown;
@@ -438,7 +441,6 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
                         const i32 w1 = clamp512k(wadd((i32)v1, (err + 16) >> 5));
                         *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2((u32)w0, (u32)w1);
                     }
-                    myrow[slotn] = s_ns[st * 4 + y];
                 } else if (type == ZT_MATCH) {                     // predictor.v:710-741
                     const i32 mask = (i32)(ht_len - 1);
                     if (mc != y) ma = 0;
