@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A clean checkout has no built artefacts (they are git-ignored): build the HIP library, the zpaqv CLI and
+    the oracle once, the same way the driver's build() does (hipcc cross-compiles without a GPU)."""
+    need = [os.path.join(ROOT, "zpaq-v_amd", "lib", "libzpaq_hip.so"), os.path.join(ROOT, "zpaq-v_amd", "bin", "zpaqv"),
+            os.path.join(ROOT, "oracle", "libzpaq_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__ as ge
+        ge.build()
+
+
 def _have_gpu():
     try:
         import torch
