@@ -22,6 +22,13 @@ def test_library_exports_every_declared_symbol(zpq):
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), "missing export: " + n
+    # the flat C surface of the C++ front end (include/zpaq_frontend.hpp, extern "C" block)
+    fe = open(os.path.join(ROOT, "include", "zpaq_frontend.hpp")).read()
+    fe = re.sub(r"/\*.*?\*/", "", fe[fe.index('extern "C" {'):], flags=re.S)
+    fnames = sorted(set(re.findall(r"\b(zpqf_[a-z0-9_]+)\s*\(", fe)))
+    assert len(fnames) >= 30
+    for n in fnames:
+        assert hasattr(L, n), "missing export: " + n
 
 
 def test_tables_match_oracle(zpq):
