@@ -79,3 +79,36 @@ def test_cli_rejects_bad_usage_without_crashing(tmp_path):
     (tmp_path / "junk.zpaq").write_bytes(os.urandom(5000))
     r = subprocess.run([cli, "l", str(tmp_path / "junk")], capture_output=True, text=True)
     assert r.returncode == 0 and "Total files: 0" in r.stdout
+
+
+def test_cli_filters_match_the_reference_known_answers():
+    """cmd/main_test.v:5-68: the reference's own tables for matches_pattern and should_include (and -mN/-sN/-tN)."""
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zpaq-v_amd", "bin", "zpaqv")
+
+    def match(s, pat):
+        args = [cli, "__match"] + ([s] if s else []) + [pat]          # an empty argv string would be dropped by the parser
+        return subprocess.run(args, capture_output=True, text=True).stdout.strip() == "true"
+
+    def include(name, only, nots):
+        args = [cli, "__include", name]
+        for o in only:
+            args += ["-only", o]
+        for n in nots:
+            args += ["-not", n]
+        return subprocess.run(args, capture_output=True, text=True).stdout.strip() == "true"
+
+    table = [("test.txt", "test.txt", True), ("test.txt", "test.doc", False), ("test.txt", "*.txt", True), ("file.txt", "*.txt", True),
+             ("test.doc", "*.txt", False), ("test.txt", "test.*", True), ("test.doc", "test.*", True), ("file.txt", "test.*", False),
+             ("abc", "*", True), ("", "*", True), ("test.txt", "tes?.txt", True), ("test.txt", "t?st.txt", True),
+             ("test.txt", "????.txt", True), ("test.txt", "???.txt", False), ("a", "?", True), ("ab", "?", False),
+             ("test123.txt", "test*.txt", True), ("test.txt", "test*.txt", True), ("testa.txt", "test?.txt", True),
+             ("test12.txt", "test?.txt", False)]
+    for s, pat, want in table:
+        assert match(s, pat) == want, (s, pat)
+    inc = [("file.txt", [], [], True), ("anything", [], [], True), ("file.txt", ["*.txt"], [], True), ("file.doc", ["*.txt"], [], False),
+           ("file.txt", ["*.txt", "*.doc"], [], True), ("file.doc", ["*.txt", "*.doc"], [], True), ("file.pdf", ["*.txt", "*.doc"], [], False),
+           ("file.txt", [], ["*.log"], True), ("file.log", [], ["*.log"], False), ("file.txt", [], ["*.log", "*.tmp"], True),
+           ("file.tmp", [], ["*.log", "*.tmp"], False), ("file.txt", ["*.txt"], ["temp*"], True), ("temp.txt", ["*.txt"], ["temp*"], False),
+           ("file.doc", ["*.txt"], ["temp*"], False)]
+    for name, only, nots, want in inc:
+        assert include(name, only, nots) == want, (name, only, nots)

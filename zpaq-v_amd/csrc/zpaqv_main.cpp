@@ -180,6 +180,11 @@ bool parse_args(int argc, char **argv, Config *cfg, std::string *err)
     else if (c == "x" || c == "extract") cfg->command = "extract";
     else if (c == "l" || c == "list") cfg->command = "list";
     else if (c == "help") { cfg->command = "help"; return true; }
+    else if (c == "__match" || c == "__include") {          // test hooks for the reference's CLI known-answer tables (cmd/main_test.v)
+        cfg->command = c;
+        cfg->files.assign(rest.begin() + 1, rest.end());
+        return true;
+    }
     else { *err = "Unknown command '" + c + "'. Use: add (a), extract (x), or list (l)"; return false; }
     if (rest.size() < 2) { *err = "Missing archive name"; return false; }
     cfg->archive = rest[1];
@@ -319,6 +324,15 @@ int main(int argc, char **argv)
     std::string err;
     if (!parse_args(argc, argv, &cfg, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     if (cfg.command == "help") { print_usage(); return 0; }
+    if (cfg.command == "__match") {
+        const bool m = cfg.files.size() == 2 ? matches_pattern(cfg.files[0], cfg.files[1]) : (cfg.files.size() == 1 ? matches_pattern("", cfg.files[0]) : false);
+        puts(m ? "true" : "false");
+        return 0;
+    }
+    if (cfg.command == "__include") {
+        puts(!cfg.files.empty() && should_include(cfg.files[0], cfg.only_files, cfg.not_files) ? "true" : "false");
+        return 0;
+    }
     if (cfg.command == "add") return run_add(cfg);
     if (cfg.command == "extract") return run_extract(cfg);
     return run_list(cfg);
