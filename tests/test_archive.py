@@ -328,3 +328,36 @@ def test_sharded_over_two_contexts_is_position_stable(zpq, gpu_ctx):
         assert [x["name"] for x in zpq.archive_extract([gpu_ctx, other], mixed, join_unnamed=True)] == [f[0] for f in files[:3] + files]
     finally:
         other.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+def test_reference_ci_scenario_directory_round_trip(tmp_path, level):
+    """The reference's own CLI acceptance run (.github/workflows/compress-decompress.yml:41-115): a directory
+    with a short text, a repetitive text, 5 KiB of random bytes, an empty file and a nested file;
+    `add archive dir/ -mN -s1`, `list`, `extract --to out -s1`, compare every file, then `-test`."""
+    d = tmp_path / "testdir"
+    (d / "subdir").mkdir(parents=True)
+    content = {
+        "simple.txt": b"Hello, ZPAQ World! This is a test file for compression.\n",
+        "repetitive.txt": b"".join(b"Line %d with repetitive content for compression testing\n" % i for i in range(1, 101)),
+        "random.bin": bytes(random.Random(level).getrandbits(8) for _ in range(5120)),
+        "empty.txt": b"",
+        "nested.txt": b"File in subdirectory\n",
+    }
+    for nm, data in content.items():
+        ((d / "subdir" / nm) if nm == "nested.txt" else (d / nm)).write_bytes(data)
+    arc = str(tmp_path / "test_archive.zpaq")
+    r = subprocess.run([CLI, "add", arc, str(d) + "/", "-m%d" % level, "-s1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files added: 5" in r.stdout and r.stdout.count("Added: ") == 5, r.stderr
+    r = subprocess.run([CLI, "list", arc], capture_output=True, text=True)
+    assert r.returncode == 0 and "Total files: 5" in r.stdout and "repetitive.txt (%d bytes)" % len(content["repetitive.txt"]) in r.stdout
+    order = [ln.split(" (")[0] for ln in r.stdout.splitlines()[2:-2]]
+    assert open(arc, "rb").read() == oracle_archive(level, [(nm, "%d bytes" % len(content[nm]), content[nm]) for nm in order])
+    out = tmp_path / "extracted"
+    r = subprocess.run([CLI, "extract", arc, "--to", str(out), "-s1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files extracted: 5" in r.stdout, r.stderr
+    for nm, data in content.items():
+        assert (out / nm).read_bytes() == data
+    r = subprocess.run([CLI, "extract", arc, "-test"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Files verified: 5" in r.stdout
