@@ -183,3 +183,41 @@ def test_no_model_header(zpq, gpu_ctx):
     assert (status == 0).all()
     assert coded[0] == O.Codec(b"", (0, 0, 0)).encode(b"\x55", pp=False)
     assert coded[1] == O.Codec(b"", (0, 0, 0)).encode(b"Hello", pp=False)
+
+
+@pytest.mark.parametrize("name", ["2", "c4b"])
+def test_first_segment_takes_the_fast_kernel_and_state_is_materialised_on_demand(zpq, gpu_ctx, name):
+    """zpq_block_*: segment 1 of a block runs on the batch kernels; only when a second segment arrives is the
+    persistent state rebuilt (replay of segment 1's symbols through the generic kernel).  Streams must equal
+    the oracle's multi-segment coding in both directions, including a decoder that sees PP bytes != 0."""
+    header = O.level_header(2) if name == "2" else C4B
+    model = zpq.Model(header=header)
+    fast = "k_chain" if name == "2" else "k_lanes"
+    segs_in = [INPUTS["text2k"][:900], b"", INPUTS["lcg4k"][:700], INPUTS["text2k"][300:1300]]
+    blk = zpq.Block(gpu_ctx, model)
+    got = []
+    for i, s in enumerate(segs_in):
+        got.append(blk.encode_segment(s))
+        assert gpu_ctx.last_kernel_name.startswith(fast if i == 0 else "k_generic"), (i, gpu_ctx.last_kernel_name)
+    blk.close()
+    # the same segments through a block that never leaves the generic kernel
+    ref = zpq.Block(gpu_ctx, model)
+    assert [ref.encode_segment(s, flags=zpq.FLAG_PP | zpq.FLAG_GENERIC) for s in segs_in] == got
+    ref.close()
+    dblk = zpq.Block(gpu_ctx, model)
+    for i, (c, s) in enumerate(zip(got, segs_in)):
+        out, cons, code, first = dblk.decode_segment(c, cap=4096)
+        assert gpu_ctx.last_kernel_name.startswith(fast if i == 0 else "k_generic")
+        assert out == s and first == 0 and cons == len(c)
+    dblk.close()
+    # first segment whose PP byte is not 0 (a PROG-mode stream): the replay must feed that byte literally
+    stream = bytes([1, 2, 0, 57, 56]) + b"payload payload"
+    e = zpq.Block(gpu_ctx, model)
+    c1, c2 = e.encode_segment(stream, flags=0), e.encode_segment(b"second", flags=zpq.FLAG_PP)
+    e.close()
+    d = zpq.Block(gpu_ctx, model)
+    out, cons, code, first = d.decode_segment(c1, cap=4096)
+    assert first == 1 and out == stream[1:]
+    out2, *_ = d.decode_segment(c2, cap=4096)
+    assert out2 == b"second"
+    d.close()

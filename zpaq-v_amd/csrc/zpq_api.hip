@@ -92,6 +92,13 @@ struct zpq_block {
     const zpq_model *model;
     uint8_t *slot;
     bool fresh;
+    // A block's FIRST segment runs on the fast batch kernels (their state lives in LDS / the shared pool and is
+    // gone afterwards).  Most blocks have exactly one segment; if a second one arrives, the persistent state in
+    // `slot` is materialised first by replaying segment 1's symbols through the generic kernel (the model state
+    // depends only on the symbol sequence, not on which direction coded it).
+    bool lazy = false;
+    std::vector<uint8_t> lazy_in;
+    uint32_t lazy_flags = 0;
 };
 
 // ------------------------------------------------------------------ ctx
@@ -494,6 +501,24 @@ extern "C" void zpq_block_destroy(zpq_block *b)
     delete b;
 }
 
+// replay the first segment into b->slot (see zpq_block): encode with no output room -- the coder only counts
+static int block_materialise(zpq_block *b)
+{
+    if (!b->lazy) return ZPQ_OK;
+    const uint64_t in_off[2] = {0, b->lazy_in.size()}, out_off[2] = {0, 0};
+    uint32_t olen = 0;
+    int32_t st = 0;
+    uint8_t dummy = 0;
+    const int rc = host_batch(b->ctx, b->model, 0, 1, b->lazy_in.data(), in_off, b->lazy_flags | ZPQ_FLAG_GENERIC, &dummy, out_off, &olen,
+                              nullptr, nullptr, nullptr, &st, b->slot, nullptr, 0, nullptr, 0);
+    if (rc != ZPQ_OK) return rc;
+    if (st != ZPQ_OK && st != ZPQ_E_OVERFLOW) return st;
+    b->lazy = false;
+    b->lazy_in.clear();
+    b->lazy_in.shrink_to_fit();
+    return ZPQ_OK;
+}
+
 extern "C" int zpq_block_encode_segment(zpq_block *b, const uint8_t *in, size_t n, uint32_t flags,
                                         uint8_t *out, size_t cap, size_t *out_len)
 {
@@ -501,6 +526,19 @@ extern "C" int zpq_block_encode_segment(zpq_block *b, const uint8_t *in, size_t 
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
     uint32_t olen = 0;
     int32_t st = 0;
+    if (b->fresh && !(flags & ZPQ_FLAG_GENERIC)) {
+        int rc = host_batch(b->ctx, b->model, 0, 1, in, in_off, flags & 0xffu, out, out_off, &olen, nullptr, nullptr,
+                            nullptr, &st, nullptr, nullptr, 0, nullptr, 0);
+        if (rc != ZPQ_OK) return rc;
+        *out_len = olen;
+        if (st != ZPQ_OK) return st;                    // nothing persisted: the block is still fresh, the caller may retry
+        b->fresh = false;
+        b->lazy = true;
+        b->lazy_in.assign(in, in + n);
+        b->lazy_flags = flags & 0xffu;
+        return ZPQ_OK;
+    }
+    if (int rcm = block_materialise(b)) return rcm;
     const uint32_t f = (flags & 0xffu) | ZPQ_FLAG_GENERIC | (b->fresh ? 0u : ZB_KEEP_STATE);
     int rc = host_batch(b->ctx, b->model, 0, 1, in, in_off, f, out, out_off, &olen, nullptr, nullptr,
                         nullptr, &st, b->slot, nullptr, 0, nullptr, 0);
@@ -518,6 +556,29 @@ extern "C" int zpq_block_decode_segment(zpq_block *b, const uint8_t *in, size_t 
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
     uint32_t olen = 0, cons = 0, code = 0, first = 0xFFFFFFFFu;
     int32_t st = 0;
+    if (b->fresh && !(flags & ZPQ_FLAG_GENERIC)) {
+        int rc = host_batch(b->ctx, b->model, 1, 1, in, in_off, flags & 0xffu, out, out_off, &olen, &cons, &code, &first,
+                            &st, nullptr, nullptr, 0, nullptr, 0);
+        if (rc != ZPQ_OK) return rc;
+        *out_len = olen;
+        if (consumed) *consumed = cons;
+        if (final_code) *final_code = code;
+        if (first_byte) *first_byte = first;
+        if (st != ZPQ_OK) return st;                    // still fresh
+        // the symbols this segment coded: [PP byte] + output.  With ZPQ_FLAG_PP the first symbol came back in `first`
+        // (0xFFFFFFFF = the stream ended before it); a later encode replays 0 as the PP byte, anything else literally.
+        b->fresh = false;
+        b->lazy = true;
+        b->lazy_in.clear();
+        b->lazy_flags = flags & 0xffu;
+        if (flags & ZPQ_FLAG_PP) {
+            if (first == 0xFFFFFFFFu) b->lazy_flags &= ~(uint32_t)ZPQ_FLAG_PP;
+            else if (first != 0) { b->lazy_flags &= ~(uint32_t)ZPQ_FLAG_PP; b->lazy_in.push_back((uint8_t)first); }
+        }
+        b->lazy_in.insert(b->lazy_in.end(), out, out + olen);
+        return ZPQ_OK;
+    }
+    if (int rcm = block_materialise(b)) return rcm;
     const uint32_t f = (flags & 0xffu) | ZPQ_FLAG_GENERIC | (b->fresh ? 0u : ZB_KEEP_STATE);
     int rc = host_batch(b->ctx, b->model, 1, 1, in, in_off, f, out, out_off, &olen, &cons, &code, &first,
                         &st, b->slot, nullptr, 0, nullptr, 0);
