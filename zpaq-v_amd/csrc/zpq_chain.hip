@@ -684,10 +684,15 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         const int want = ev ? atoi(ev) : ZPQ_CHAIN_G_DEFAULT;
         cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
     }
+    cfg->dbg_ht_and = 0xFFFFFFFFu;
+#ifdef ZPQ_DEBUG_KNOBS
     {
-        const char *ev = getenv("ZPQ_DEBUG_HT_AND");     // WRONG RESULTS: cache-resident tables, timing only
-        cfg->dbg_ht_and = ev ? (uint32_t)strtoul(ev, nullptr, 0) : 0xFFFFFFFFu;
+        // timing experiments only (make EXTRA=-DZPQ_DEBUG_KNOBS): an AND-mask on hash-table offsets keeps the tables
+        // cache-resident -- the output is WRONG, which is why a normal build cannot reach this
+        const char *ev = getenv("ZPQ_DEBUG_HT_AND");
+        if (ev) cfg->dbg_ht_and = (uint32_t)strtoul(ev, nullptr, 0);
     }
+#endif
     // Per-block LDS layout.  Tables are indexed by the bit-history state, and lanes of
     // different blocks / components very often hold EQUAL states, so tables whose bases share
     // a bank (all of them, if laid out at 1 KiB multiples) collide on every access -- rocprof
