@@ -45,6 +45,29 @@ private:
     std::vector<uint8_t> data_;
 };
 
+// io.v:113-185: a byte buffer that is both a Reader and a Writer
+class StringBuffer : public Reader, public Writer {
+public:
+    StringBuffer() : read_pos_(0) {}
+    explicit StringBuffer(std::vector<uint8_t> data) : data_(std::move(data)), read_pos_(0) {}       // from_bytes
+    int get() override { return read_pos_ < data_.size() ? data_[read_pos_++] : -1; }
+    void put(int c) override { data_.push_back((uint8_t)c); }
+    const std::vector<uint8_t> &bytes() const { return data_; }
+    int len() const { return (int)data_.size(); }
+    void reset_read() { read_pos_ = 0; }
+    void clear() { data_.clear(); read_pos_ = 0; }
+private:
+    std::vector<uint8_t> data_;
+    size_t read_pos_;
+};
+
+// io.v:24-37 (to_u32 keeps the reference's Go-style precedence: p[0] + (p[1] << 8) + ...)
+inline int to_u16(const uint8_t *p, size_t n) { return n < 2 ? 0 : (int)p[0] + (int)p[1] * 256; }
+inline uint32_t to_u32(const uint8_t *p, size_t n)
+{
+    return n < 4 ? 0u : (uint32_t)p[0] + ((uint32_t)p[1] << 8) + ((uint32_t)p[2] << 16) + ((uint32_t)p[3] << 24);
+}
+
 // sha1.v:6-146
 class SHA1 {
 public:
