@@ -338,28 +338,28 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
         u8 *n_pa = ht;
         u32 n_chk = 0, sp_claims = 0;
+        u32 n_key = 0, n_si = 0, n_tag = 0, n_off = 0;     // compact store: the probe in flight
+        auto sp_claim = [&](const u32 si, const u32 key) {   // a free slot becomes this line's (its 64 bytes are still zero)
+            if (sp_claims * 10u >= (sp_mask + 1u) * 9u) { status = ZPQ_E_TOOBIG; return; }   // store (nearly) full
+            sp_tags[si] = key;
+            sp_claims++;
+        };
         auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
             const u32 cx = hc + 16u * c8v;
             n_chk = (cx >> sizebits) & 255u;
             const u32 h0 = (cx * 16u) & ht_mask;
             u8 *pa = ht + h0;
             if (sp_log2) {
-                // dense line index -> slot of the compact store (open addressing, linear probing);
-                // a free slot is claimed, its line is still all-zero like an untouched dense line
-                const u32 key = (h0 >> 6) + 1u;
-                u32 si = ((h0 >> 6) * 0x9E3779B1u) >> (32u - sp_log2);
-                for (u32 tries = 0; tries <= sp_mask; tries++) {
-                    const u32 t = sp_tags[si];
-                    if (t == key) break;
-                    if (t == 0u) {
-                        if (sp_claims * 10u >= (sp_mask + 1u) * 9u) { status = ZPQ_E_TOOBIG; break; }  // store (nearly) full
-                        sp_tags[si] = key;
-                        sp_claims++;
-                        break;
-                    }
-                    si = (si + 1u) & sp_mask;
-                }
-                pa = sp_lines + ((u64)si << 6) + (h0 & 48u);
+                // dense line index -> slot of the compact store (open addressing, linear probing from a
+                // multiplicative hash).  The FIRST slot's rows are fetched together with its tag: when the tag
+                // turns out to be this line's, or free (claimed in take_prefetched; a free slot's line is still
+                // all-zero like an untouched dense line), that was the only memory round trip.  Only a real
+                // collision walks on, serially, in take_prefetched.
+                n_key = (h0 >> 6) + 1u;
+                n_si = ((h0 >> 6) * 0x9E3779B1u) >> (32u - sp_log2);
+                n_off = h0 & 48u;
+                n_tag = sp_tags[n_si];
+                pa = sp_lines + ((u64)n_si << 6) + n_off;
             }
             n_pa = pa;
             nA = *reinterpret_cast<const u32x4 *>(pa);
@@ -371,6 +371,23 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
         // is one of the candidates.
         auto take_prefetched = [&](const bool have_prev) {
+            if (sp_log2 && n_tag != n_key) {                  // compact store: the first slot was not (yet) this line's
+                u32 si = n_si;
+                if (n_tag == 0u) sp_claim(si, n_key);
+                else {
+                    for (u32 tries = 0; tries < sp_mask; tries++) {
+                        si = (si + 1u) & sp_mask;
+                        const u32 t = sp_tags[si];
+                        if (t == n_key) break;
+                        if (t == 0u) { sp_claim(si, n_key); break; }
+                    }
+                    u8 *pa = sp_lines + ((u64)si << 6) + n_off;
+                    n_pa = pa;
+                    nA = *reinterpret_cast<const u32x4 *>(pa);
+                    nB = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);
+                    nC = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
+                }
+            }
             const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
             u8 *const paddr = raddr;
             const uintptr_t na = reinterpret_cast<uintptr_t>(n_pa), pp = reinterpret_cast<uintptr_t>(paddr);
