@@ -442,8 +442,33 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             cur_pst = icm_st(cur_v, cur_b);
         };
 
-        auto bitstep = [&](auto kc, const int bit) {
+        // MIX2 weights when ENCODING (levels 4-5): cxt = (h[i] + (c8 & mask)) & (size-1) (predictor.v:587-592) with
+        // mask = 255 walks eight DISTINCT entries per byte -- c8 = 1, 1b7, 1b7b6, ... -- all known when the byte
+        // begins.  They are loaded into registers there, BEFORE the row prefetch is issued, trained in registers and
+        // written back when the next byte begins.  A global load inside the bit steps would be waited for with the
+        // in-order vmcnt, i.e. together with the row prefetch issued before it, exposing that HBM fetch every nibble.
+        // Lanes other than the MIX2's aim the same (unconditional, so the compiler can count them) accesses at one
+        // scratch word per workgroup.
+        const bool mixreg = has_mix2 && (mix_mask & 255u) == 255u && mix_cmask >= 255u;
+        u32 mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32 mh_prev = 0, mch_prev = 0;
+        u16 *const ax16 = (ctype == ZT_MIX2) ? a16
+                                             : reinterpret_cast<u16 *>(B.slots + (u64)(blockIdx.x * cfg.blocks_per_wg) * M.slot_bytes + M.comp[0].cm_off);
+        const u32 axmask = (ctype == ZT_MIX2) ? mix_cmask : 0u;
+        auto mix_byte_begin = [&](const u32 byte, const bool have_prev) {
+            if (have_prev) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) ax16[(mh_prev + ((1u << t) | (mch_prev >> (8 - t)))) & axmask] = (u16)mw[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) mw[t] = ax16[(hctx + ((1u << t) | (byte >> (8 - t)))) & axmask];
+            mh_prev = hctx;
+            mch_prev = byte;
+        };
+
+        auto bitstep = [&](auto kc, auto nbc) {
             constexpr int K = decltype(kc)::value;
+            constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;   // bit of the byte this step codes (7..0)
             // (plain form: cur_* of bits 1..3 were fetched at the end of the previous bit step, see (4b))
             const u32 s = cur_s;
             const i32 yk = DEC ? 0 : (i32)((ch >> bit) & 1u);  // encode knows its bit up front
@@ -486,7 +511,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             if (has_mix2) {
                 pj = row_bcast(p, row_base + mix_j);
                 pk = row_bcast(p, row_base + mix_k);
-                if (is_last) {
+                if (!DEC && mixreg) {
+                    // encode: the byte's eight weights sit in registers since the byte began (mix_byte_begin)
+                    wmix = (i32)mw[7 - bit];
+                    if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                } else if (is_last) {
                     mcx = (hctx + (X.c8 & mix_mask)) & mix_cmask;
                     wmix = a16[mcx];
                     p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
@@ -560,7 +589,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
-                a16[mcx] = (u16)w;
+                if (!DEC && mixreg) mw[7 - bit] = (u32)w;
+                else a16[mcx] = (u16)w;
             }
             // ---- (6) hand the next bit its state, forwarded entry and stretch
             if (SPEC && K < 3) {
@@ -627,22 +657,23 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             X.c8 = 1; X.slot = 1;
             u32 hnext = 0;
             take_prefetched(bi != 0);                         // rows of this byte's first nibble
+            if (!DEC && mixreg) mix_byte_begin(ch, bi != 0);  // (before the prefetch below, see mix_byte_begin)
             if (!DEC) {
                 hnext = run_vm(ch);                           // contexts of the NEXT byte: known now
                 prefetch_rows(hctx, 16u | (ch >> 4));         // second nibble of this byte, a nibble ahead
             }
             nibble_begin();
-            bitstep(std::integral_constant<int, 0>{}, 7);
-            bitstep(std::integral_constant<int, 1>{}, 6);
-            bitstep(std::integral_constant<int, 2>{}, 5);
-            bitstep(std::integral_constant<int, 3>{}, 4);     // decode: requests the next rows inside
+            bitstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            bitstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            bitstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+            bitstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
             take_prefetched(true);
             if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();
-            bitstep(std::integral_constant<int, 0>{}, 3);
-            bitstep(std::integral_constant<int, 1>{}, 2);
-            bitstep(std::integral_constant<int, 2>{}, 1);
-            bitstep(std::integral_constant<int, 3>{}, 0);
+            bitstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            bitstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            bitstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            bitstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
             const u32 byte = X.c8 - 256;
             hctx = DEC ? hnext_dec : hnext;
 
