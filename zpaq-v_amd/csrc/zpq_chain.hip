@@ -83,6 +83,7 @@ struct Cfg {
     int32_t nch_spec;          // compile-time specialisation picked on the host: chain length (0 = runtime path)
     uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
+    int32_t lds_mixw;          // byte offset inside the block's LDS state of u16[16]: the nibble's candidate MIX2 weights (decode)
     uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
     uint16_t lds_off8[G];      // ISSE c's u8 table (w1 bits 12..19); 0xFFFF = none
 };
@@ -196,7 +197,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     u8 *ht = hashed ? slot + C.ht_off : slot;
     const u32 ht_mask = hashed ? ((C.ht_len - 16u) & cfg.dbg_ht_and) : 0u;
     // compact line store (levels 4-5): tags[cap] + 64-byte lines[cap] instead of the dense table
-    const u32 sp_log2 = hashed ? C.sp_cap_log2 : 0u;
+    // Only the kernels that can meet a compact store carry its code (the MIX2 levels 4-5 and the runtime-loop
+    // kernel); in the dense-table kernels of levels 1-3 the mere presence of its collision walk -- a divergent
+    // branch with global loads inside take_prefetched -- cost 17 % of encode (measured: 251 -> 293 ms).
+    constexpr bool SPARSE = (NCH == 0) || MIXT;
+    const u32 sp_log2 = (SPARSE && hashed) ? C.sp_cap_log2 : 0u;
     u32 *sp_tags = reinterpret_cast<u32 *>(slot + C.sp_tag_off);
     u8 *sp_lines = slot + C.sp_line_off;
     const u32 sp_mask = sp_log2 ? ((1u << sp_log2) - 1u) : 0u;
@@ -466,6 +471,48 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             mch_prev = byte;
         };
 
+        // MIX2 weights when DECODING: the contexts of a nibble are not known ahead, but there are only 15 candidates
+        // (c8 = prefix extended by 0..3 bits = the same slot numbering 1..15 as the bit-history row).  The group's
+        // lanes fetch them together with the nibble's rows (lane l takes slots l and l+G..), park them in LDS, the MIX2
+        // lane reads and trains its weight there, and the lanes write their candidates back when the nibble ends.
+        u16 *const w16s = reinterpret_cast<u16 *>(my + cfg.lds_mixw);
+        u16 *const a16m = reinterpret_cast<u16 *>(slot + M.comp[last].a16_off);
+        constexpr int MQ = 16 / GG;
+        u32 mwa[MQ], mwl[MQ];
+#pragma unroll
+        for (int q = 0; q < MQ; q++) { mwa[q] = 0; mwl[q] = 0; }
+        bool mix_live = false;                              // candidates of the current nibble are in w16s
+        // `prefix` = c8 at the start of the nibble (1, or 1hhhh); `hm` = the MIX2 component's context hash
+        auto mixw_request = [&](const u32 hm, const u32 prefix) {
+            // all write-backs first, then all loads: an entry of the nibble that just ended may be a candidate of
+            // the next one under another lane (the index is a hash), and must be re-read with its trained value
+            if (mix_live) {
+#pragma unroll
+                for (int q = 0; q < MQ; q++) {
+                    const u32 sl = (u32)li + (u32)q * GG;    // this lane's slot (0 = none)
+                    if (sl >= 1u && sl <= 15u) a16m[mwa[q]] = w16s[sl];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MQ; q++) {
+                const u32 sl = (u32)li + (u32)q * GG;
+                if (sl >= 1u && sl <= 15u) {
+                    const u32 L = 31u - (u32)__clz((int)sl);
+                    const u32 c8c = (prefix << L) | (sl - (1u << L));
+                    mwa[q] = (hm + (c8c & mix_mask)) & mix_cmask;
+                    mwl[q] = a16m[mwa[q]];
+                }
+            }
+            mix_live = true;
+        };
+        auto mixw_arrive = [&]() {                          // after take_prefetched: the loads have landed
+#pragma unroll
+            for (int q = 0; q < MQ; q++) {
+                const u32 sl = (u32)li + (u32)q * GG;
+                if (sl >= 1u && sl <= 15u) w16s[sl] = (u16)mwl[q];
+            }
+        };
+
         auto bitstep = [&](auto kc, auto nbc) {
             constexpr int K = decltype(kc)::value;
             constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;   // bit of the byte this step codes (7..0)
@@ -514,6 +561,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 if (!DEC && mixreg) {
                     // encode: the byte's eight weights sit in registers since the byte began (mix_byte_begin)
                     wmix = (i32)mw[7 - bit];
+                    if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                } else if (DEC && mixreg) {
+                    wmix = (i32)w16s[X.slot];
                     if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
                 } else if (is_last) {
                     mcx = (hctx + (X.c8 & mix_mask)) & mix_cmask;
@@ -590,7 +640,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
                 if (!DEC && mixreg) mw[7 - bit] = (u32)w;
+                else if (DEC && mixreg) w16s[X.slot] = (u16)w;
                 else a16[mcx] = (u16)w;
+            }
+            if (DEC && K == 3 && mixreg) {
+                // this nibble's weights are final: write the candidates back and request the next nibble's
+                // (after the update above; stores before loads, an entry may recur under another context hash)
+                // (hash and prefix from the coder lane: idle lanes above it never see the decoded bits)
+                const u32 c8n2 = (u32)row_bcast((i32)((X.c8 << 1) | (u32)y), row_base + last);
+                if (bit == 4) mixw_request(row_bcast((i32)hctx, row_base + last), c8n2);
+                else mixw_request(row_bcast((i32)hnext_dec, row_base + last), 1u);
             }
             // ---- (6) hand the next bit its state, forwarded entry and stretch
             if (SPEC && K < 3) {
@@ -625,6 +684,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
 
         prefetch_rows(0u, 1u);                             // first nibble of the first byte: h = 0, c8 = 1
+        if (DEC && mixreg) mixw_request(0u, 1u);
         for (u32 bi = 0; bi < total; bi++) {
             if (!DEC) {
                 if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : in_byte(bi - 1);
@@ -657,6 +717,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             X.c8 = 1; X.slot = 1;
             u32 hnext = 0;
             take_prefetched(bi != 0);                         // rows of this byte's first nibble
+            if (DEC && mixreg) mixw_arrive();
             if (!DEC && mixreg) mix_byte_begin(ch, bi != 0);  // (before the prefetch below, see mix_byte_begin)
             if (!DEC) {
                 hnext = run_vm(ch);                           // contexts of the NEXT byte: known now
@@ -668,6 +729,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             bitstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
             bitstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
             take_prefetched(true);
+            if (DEC && mixreg) mixw_arrive();
             if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();
             bitstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -769,10 +831,14 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         if (M->comp[i].j >= i || M->comp[i].k >= i) return false;
         cfg->has_mix2 = 1;
         cfg->lds_off32[i] = 0;
+        cfg->lds_mixw = place(32, i);
     }
     {
         const int nch = cfg->nisse_end;
-        const bool spec = cfg->has_mix2 ? (nch == 6 || nch == 8) : (nch == 2 || nch == 3 || nch == 5);
+        bool spec = cfg->has_mix2 ? (nch == 6 || nch == 8) : (nch == 2 || nch == 3 || nch == 5);
+        bool any_sparse = false;
+        for (int c = 0; c < M->n; c++) any_sparse = any_sparse || M->comp[c].sp_cap_log2 != 0;
+        if (any_sparse && !cfg->has_mix2) spec = false;       // the plain-chain kernels are dense-only: use the runtime-loop kernel
         cfg->nch_spec = spec ? nch : 0;
         if (spec) cfg->g = (M->n <= 8) ? 8 : 16;              // specialised kernels exist for one G each
     }
