@@ -344,3 +344,24 @@ def test_other_levels_at_baseline_block_size(zpq, gpu_ctx, level, nb):
     want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
     for i, w in zip(sample, want):
         assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+
+
+@pytest.mark.parametrize("level", [4, 5])
+def test_mix2_levels_ragged_batch_with_slot_reuse(zpq, gpu_ctx, level):
+    """Levels 4-5 keep the MIX2 weights out of the bit loop (encode: the byte's eight weights in registers,
+    decode: the nibble's fifteen candidates in LDS).  Ragged batch of all data classes, fewer slots than blocks
+    (that per-block state must start clean every time), empty and one-byte blocks."""
+    model = zpq.Model(level=level)
+    rnd = random.Random(90 + level)
+    blocks = [bytes(W.make_block(3 * b + level, rnd.choice([0, 1, 2, 15, 16, 17, 300, 1500, 4000]))) for b in range(14)]
+    want = O.encode_blocks(model.header, blocks, nthreads=4)
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 450 << 20)      # 3-4 slots of the compact layout (104 / 141 MiB)
+    try:
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name == "k_chain<encode>" and gpu_ctx.last_slots <= 5
+        assert (status == 0).all() and coded == want
+        dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, coded, cap=8192)
+        assert gpu_ctx.last_kernel_name == "k_chain<decode>"
+        assert (status == 0).all() and dec == blocks and (first == 0).all()
+    finally:
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
