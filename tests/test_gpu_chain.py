@@ -365,3 +365,26 @@ def test_mix2_levels_ragged_batch_with_slot_reuse(zpq, gpu_ctx, level):
         assert (status == 0).all() and dec == blocks and (first == 0).all()
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+
+
+@pytest.mark.parametrize("level", [4, 5])
+def test_mix2_weight_aliasing_stress(zpq, gpu_ctx, level):
+    """The MIX2 weight index is a hash: consecutive nibbles may reach the same weight under different slots (and so,
+    in the decoder, under different lanes).  Shrinking the level's MIX2 table to 256 entries makes that happen all
+    the time; the decoder must then forward the trained value instead of re-reading memory."""
+    h = bytearray(O.level_header(level))
+    sz = [0, 2, 3, 2, 3, 4, 6, 6, 3, 5]
+    p = 5
+    for _ in range(h[4]):
+        if h[p] == 6:
+            h[p + 1] = 8                      # sizebits: 256 weights (still >= 256, mask stays 255)
+        p += sz[h[p]]
+    header = bytes(h)
+    model = zpq.Model(header=header)
+    assert model.has_fast_path
+    blocks = [bytes(W.make_block(b, 3000 + 500 * (b % 3))) for b in range(12)]
+    want = O.encode_blocks(header, blocks, nthreads=4)
+    coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert gpu_ctx.last_kernel_name == "k_chain<encode>" and (status == 0).all() and coded == want
+    dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, coded, cap=8192)
+    assert (status == 0).all() and dec == blocks

@@ -410,12 +410,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
         auto run_vm = [&](const u32 byte) -> u32 {
             u32 hv = 0;
-            if (cfg.vm_kind == VM_HASHCHAIN) {
+            // the specialised kernels are only launched for their level's own program shape (chain of 2 = level 1's
+            // program, longer chains = the hash chain): the interpreter and its state exist only in the runtime-loop kernel
+            const int vm_kind = NCH == 0 ? cfg.vm_kind : (NCH == 2 ? (int)VM_LEVEL1 : (int)VM_HASHCHAIN);
+            if (vm_kind == VM_HASHCHAIN) {
                 // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
                 u32 a = byte;
                 for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
                 prev = byte;
-            } else if (cfg.vm_kind == VM_LEVEL1) {
+            } else if (vm_kind == VM_LEVEL1) {
                 // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
                 m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
                 u32 a = 0;
@@ -454,7 +457,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // in-order vmcnt, i.e. together with the row prefetch issued before it, exposing that HBM fetch every nibble.
         // Lanes other than the MIX2's aim the same (unconditional, so the compiler can count them) accesses at one
         // scratch word per workgroup.
-        const bool mixreg = has_mix2 && (mix_mask & 255u) == 255u && mix_cmask >= 255u;
+        // (the specialised MIX2 kernels are only launched when this holds; the runtime-loop kernel checks it)
+        const bool mixreg = NCH ? MIXT : (has_mix2 && (mix_mask & 255u) == 255u && mix_cmask >= 255u);
         u32 mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         u32 mh_prev = 0, mch_prev = 0;
         u16 *const ax16 = (ctype == ZT_MIX2) ? a16
@@ -478,38 +482,47 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u16 *const w16s = reinterpret_cast<u16 *>(my + cfg.lds_mixw);
         u16 *const a16m = reinterpret_cast<u16 *>(slot + M.comp[last].a16_off);
         constexpr int MQ = 16 / GG;
-        u32 mwa[MQ], mwl[MQ];
+        u32 mwa[MQ], mwl[MQ], mwf[MQ];
+        bool mwhit[MQ];
 #pragma unroll
-        for (int q = 0; q < MQ; q++) { mwa[q] = 0; mwl[q] = 0; }
+        for (int q = 0; q < MQ; q++) { mwa[q] = 0; mwl[q] = 0; mwf[q] = 0; mwhit[q] = false; }
         bool mix_live = false;                              // candidates of the current nibble are in w16s
+        u32 mix_hm = 0, mix_prefix = 1;                     // what the current nibble's candidates were derived from
         // `prefix` = c8 at the start of the nibble (1, or 1hhhh); `hm` = the MIX2 component's context hash
         auto mixw_request = [&](const u32 hm, const u32 prefix) {
-            // all write-backs first, then all loads: an entry of the nibble that just ended may be a candidate of
-            // the next one under another lane (the index is a hash), and must be re-read with its trained value
-            if (mix_live) {
-#pragma unroll
-                for (int q = 0; q < MQ; q++) {
-                    const u32 sl = (u32)li + (u32)q * GG;    // this lane's slot (0 = none)
-                    if (sl >= 1u && sl <= 15u) a16m[mwa[q]] = w16s[sl];
-                }
-            }
+            const u32 plen_old = 32u - (u32)__clz((int)mix_prefix);      // bit length of the old prefix (1 or 5)
 #pragma unroll
             for (int q = 0; q < MQ; q++) {
-                const u32 sl = (u32)li + (u32)q * GG;
+                const u32 sl = (u32)li + (u32)q * GG;        // this lane's slot (0 = none)
                 if (sl >= 1u && sl <= 15u) {
+                    if (mix_live) a16m[mwa[q]] = w16s[sl];   // the nibble that just ended (values are final)
                     const u32 L = 31u - (u32)__clz((int)sl);
                     const u32 c8c = (prefix << L) | (sl - (1u << L));
-                    mwa[q] = (hm + (c8c & mix_mask)) & mix_cmask;
-                    mwl[q] = a16m[mwa[q]];
+                    const u32 na = (hm + (c8c & mix_mask)) & mix_cmask;
+                    // The index is a hash: this entry may have been a candidate of the nibble that just ended,
+                    // under ANOTHER lane.  That lane's write-back and this lane's load are not ordered against
+                    // each other, so such an entry is taken from LDS, where its trained value still sits:
+                    // d = na - old hash must read (old prefix << Lo) | r with Lo = 0..3, r < 2^Lo.
+                    const u32 d = (na - mix_hm) & mix_cmask;
+                    const u32 dlen = 32u - (u32)__clz((int)(d | 1u));
+                    const u32 Lo = dlen - plen_old;
+                    const bool in_old = mix_live && d != 0u && d <= 255u && dlen >= plen_old && Lo <= 3u && (d >> Lo) == mix_prefix;
+                    const u32 so = (1u << (Lo & 3u)) | (d & ((1u << (Lo & 3u)) - 1u));
+                    mwhit[q] = in_old;
+                    mwf[q] = w16s[in_old ? so : 0u];
+                    mwa[q] = na;
+                    mwl[q] = a16m[na];
                 }
             }
             mix_live = true;
+            mix_hm = hm;
+            mix_prefix = prefix;
         };
         auto mixw_arrive = [&]() {                          // after take_prefetched: the loads have landed
 #pragma unroll
             for (int q = 0; q < MQ; q++) {
                 const u32 sl = (u32)li + (u32)q * GG;
-                if (sl >= 1u && sl <= 15u) w16s[sl] = (u16)mwl[q];
+                if (sl >= 1u && sl <= 15u) w16s[sl] = (u16)(mwhit[q] ? mwf[q] : mwl[q]);
             }
         };
 
@@ -853,6 +866,15 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         static const uint8_t l1[] = {96, 4, 28, 59, 10, 59, 112, 25, 10, 59, 10, 59, 112, 56};
         if (plen == (int)sizeof l1 && memcmp(p, l1, sizeof l1) == 0 && M->mlen == 4 && M->hlen == 2 && M->n == 2)
             cfg->vm_kind = zpqc::VM_LEVEL1;
+    }
+    // a specialised kernel evaluates exactly one program shape in registers and, with a MIX2, keeps its weights out
+    // of the bit loop (needs mask 255 and >= 256 weights); anything else -> runtime-loop kernel
+    const bool mix_ok = !cfg->has_mix2 || ((M->comp[M->n - 1].mask & 255) == 255 && M->comp[M->n - 1].c >= 256);
+    if (cfg->nch_spec && (!mix_ok || cfg->vm_kind != (cfg->nch_spec == 2 ? zpqc::VM_LEVEL1 : zpqc::VM_HASHCHAIN))) {
+        cfg->nch_spec = 0;
+        const char *ev = getenv("ZPQ_CHAIN_G");
+        const int want = ev ? atoi(ev) : ZPQ_CHAIN_G_DEFAULT;
+        cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
     }
     const int bpwave2 = 64 / cfg->g;   // blocks one wave carries
     const int avail = 160 * 1024 - zpqc::LDS_STATE - 1280 /*dummy tables*/ - 256;
