@@ -93,7 +93,9 @@ __device__ __forceinline__ i32 wave_sum(i32 x)
 __device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
 __device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
 
-template <bool DEC>
+// VMH: the program is the shipped hash chain (cfg.vm_hashes > 0), evaluated in registers -- such launches do not carry
+// the ZPAQL interpreter at all (fewer registers, no spills); any other program runs through it on lane 0.
+template <bool DEC, bool VMH>
 __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const LCfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_lanes(const DBatch B, const L
             LPROF(5);
             const u32 byte = c8 - 256;
             // ---- ZPAQL.run(byte); h[i] = z.h[i] (predictor.v:809-816)
-            if (cfg.vm_hashes > 0) {
+            if (VMH) {
                 // H[k] = hash^(k+1)(byte, previous byte), hash: a = (a + *b + 512) * 773 (zpaql.v HASH);
                 // every lane walks the chain and keeps its own link
                 u32 a = byte, hv = 0;
@@ -605,7 +607,7 @@ extern "C" int zpq_lanes_supported(const DModel *M)
 extern "C" int zpq_lanes_blocks_per_cu(const DModel *)
 {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)zpql::k_lanes<false>, 64 * zpql::WAVES,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)zpql::k_lanes<false, false>, 64 * zpql::WAVES,
                                                      zpql::LDS_TOTAL) != hipSuccess || nb < 1)
         nb = 2;
     return nb * zpql::WAVES;
@@ -616,7 +618,13 @@ extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode
     zpql::LCfg cfg;
     if (!lanes_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     const int grid = (nslots + zpql::WAVES - 1) / zpql::WAVES;
-    if (decode) hipLaunchKernelGGL(zpql::k_lanes<true>, dim3(grid), dim3(64 * zpql::WAVES), zpql::LDS_TOTAL, stream, *B, cfg);
-    else hipLaunchKernelGGL(zpql::k_lanes<false>, dim3(grid), dim3(64 * zpql::WAVES), zpql::LDS_TOTAL, stream, *B, cfg);
+    const dim3 g(grid), t(64 * zpql::WAVES);
+    if (cfg.vm_hashes > 0) {
+        if (decode) hipLaunchKernelGGL((zpql::k_lanes<true, true>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+        else hipLaunchKernelGGL((zpql::k_lanes<false, true>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+    } else {
+        if (decode) hipLaunchKernelGGL((zpql::k_lanes<true, false>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+        else hipLaunchKernelGGL((zpql::k_lanes<false, false>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+    }
     return ZPQ_OK;
 }
