@@ -587,12 +587,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li]) (predictor.v:193-202,667)
             // ---- (3) off the critical path: the ICM's stretch for the next bit, for both
             //          outcomes, with this bit's cm update forwarded when the state repeats
-            const u32 cm0 = (u32)wadd((i32)cmv, (0 - (i32)(cmv >> 8)) >> 2);       // y = 0 (predictor.v:706-708)
-            const u32 cm1 = (u32)wadd((i32)cmv, (32767 - (i32)(cmv >> 8)) >> 2);   // y = 1
+            // cm += (y*32767 - (cm >> 8)) >> 2 (predictor.v:706-708).  Encode knows y and computes one outcome; the
+            // speculative decoder wants both ahead of the coder; the plain decoder computes its one after the bit.
+            auto cm_next = [&](const i32 yy) -> u32 { return (u32)wadd((i32)cmv, ((yy ? 32767 : 0) - (i32)(cmv >> 8)) >> 2); };
+            const u32 cm0 = (DEC && SPEC) ? cm_next(0) : 0u, cm1 = (DEC && SPEC) ? cm_next(1) : 0u;
+            u32 cmn = DEC ? 0u : cm_next(yk);
             // the trained entry's stretch travels with it; encode knows y already, so it is computed here,
             // off the path to the coder; decode computes it after the bit is known
             i32 stA = 0, stB = 0, st0 = 0, st1 = 0, st_new = 0;
-            if (!DEC) st_new = stretch_lds(yk ? cm1 : cm0);
+            if (!DEC) st_new = stretch_lds(cmn);
             else if (SPEC) { st0 = stretch_lds(cm0); st1 = stretch_lds(cm1); }
             if (SPEC && K < 3) {
                 if (DEC) {
@@ -643,8 +646,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 err = (y ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));  // |err|<2^15, |pin|<=2^11
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-            if (DEC) st_new = SPEC ? (y ? st1 : st0) : stretch_lds(y ? cm1 : cm0);   // (both outcomes ahead of the coder: measured slower)
-            const u32 nv = is_icm ? ((y ? cm1 : cm0) | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
+            if (DEC) {
+                cmn = SPEC ? (y ? cm1 : cm0) : cm_next(y);
+                st_new = SPEC ? (y ? st1 : st0) : stretch_lds(cmn);            // (both outcomes ahead of the coder: measured slower)
+            }
+            const u32 nv = is_icm ? (cmn | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
             const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
             t32[s] = nv;
             t8[s] = (u8)nb;
