@@ -12,8 +12,19 @@ resident in HBM).  value = uncompressed MB / (t_comp + t_decomp), whole job.
 One rank per GPU; block b of the global batch goes to rank b mod N (static
 round-robin, no data-path collective); timing is barrier + synchronize on both
 sides, MAX over ranks; rank 0 prints ONE JSON line.
+
+After the timed headline, at N = 1 only and outside the timed region, the same
+line gains:
+  per_class        the headline workload one block class at a time
+  value_incl_pcie  the same batch through the host-pointer entry points
+                   (H2D + kernel + D2H inside the call)
+  secondary        C2 (level 1, 4096 blocks), levels 3-4, C4a (level 5 at its
+                   resident capacity) and C4b (all nine component types), each
+                   with its own roofline
+  cpu_baseline     the C oracle on this host at nproc (<= 16) threads and at 1 thread
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,35 +34,144 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALG_BYTES_PER_INPUT_BYTE_L = {1: 131, 2: 195, 3: 323, 4: 419, 5: 547}   # A(L) = this + r
+# A(L) = 1 + r + 64*K_h + 2 + 32*[MIX2]; the table holds A(L) - r
+ALG_BYTES_PER_INPUT_BYTE_L = {1: 131, 2: 195, 3: 323, 4: 419, 5: 547}
+ALG_BYTES_C4B = 211
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+LEVEL_NAMES = {1: "ICM16+ISSE19", 2: "ICM16+ISSE16+ISSE16", 3: "ICM18+4xISSE18", 4: "ICM20+5xISSE20+MIX2",
+               5: "ICM22+7xISSE22+MIX2"}
 
 
-def cpu_baseline(level, size, per_thread_blocks=24):
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(level, size, per_thread_blocks, one_thread_blocks):
     """The C oracle (a restatement of the V CPU path -- V itself cannot be built
     here) timed on this host: compress+decompress of a bounded sample of the same
-    synthetic blocks, blocks divided statically over `cores` pthreads."""
-    import numpy as np
+    synthetic blocks, blocks divided statically over `cores` pthreads; then the
+    same at one thread."""
     import oracle_lib as O
     import workload as W
-    cores = min(os.cpu_count() or 1, 16)
-    nb = per_thread_blocks * cores
-    arr = W.make_blocks_fast(nb, size)
-    blocks = [arr[i].tobytes() for i in range(nb)]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     hdr = O.level_header(level)
-    t0 = time.time()
-    coded = O.encode_blocks(hdr, blocks, nthreads=cores, slack=size + size // 8 + 1024)
-    t1 = time.time()
-    dec = O.decode_blocks(hdr, coded, cap=size + 16, nthreads=cores)
-    t2 = time.time()
-    assert dec == [b"\0" + b for b in blocks]
-    B = nb * size
+
+    def timed(nb, nthreads):
+        arr = W.make_blocks_fast(nb, size)
+        blocks = [arr[i].tobytes() for i in range(nb)]
+        t0 = time.time()
+        coded = O.encode_blocks(hdr, blocks, nthreads=nthreads, slack=size + size // 8 + 1024)
+        t1 = time.time()
+        dec = O.decode_blocks(hdr, coded, cap=size + 16, nthreads=nthreads)
+        t2 = time.time()
+        assert dec == [b"\0" + b for b in blocks]
+        B = nb * size
+        return B / (t2 - t0) / 1e6, B / (t1 - t0) / 1e6, B / (t2 - t1) / 1e6, t2 - t0
+
+    nb = per_thread_blocks * cores
+    v, vc, vd, secs = timed(nb, cores)
+    v1, vc1, vd1, secs1 = timed(one_thread_blocks, 1)
     return {
-        "value": round(B / (t2 - t0) / 1e6, 3), "unit": "MB/s", "cores": cores, "kind": "port",
-        "comp_MBps": round(B / (t1 - t0) / 1e6, 3), "decomp_MBps": round(B / (t2 - t1) / 1e6, 3),
+        "value": round(v, 3), "unit": "MB/s", "cores": cores, "kind": "port",
+        "comp_MBps": round(vc, 3), "decomp_MBps": round(vd, 3), "seconds": round(secs, 2),
+        "one_thread": {"value": round(v1, 3), "comp_MBps": round(vc1, 3), "decomp_MBps": round(vd1, 3),
+                       "blocks": one_thread_blocks, "seconds": round(secs1, 2)},
+        "nproc": os.cpu_count(), "nproc_available": avail, "cpu_model": cpu_model_string(),
         "sample": "%d synthetic 64 KiB blocks (same generator, classes b mod 4), level %d, C oracle "
-                  "compress+decompress, %d pthreads, per-block table alloc+zero-fill included" % (nb, level, cores),
+                  "compress+decompress, %d pthreads (blocks divided statically), per-block table alloc+zero-fill "
+                  "included; one_thread = the first %d of those blocks on 1 thread.  A real V build adds bounds "
+                  "checks and interface dispatch per byte, so it would be slower than this port." % (
+                      nb, level, cores, one_thread_blocks),
     }
+
+
+class ResidentBatch:
+    """nb blocks of `size` bytes resident in HBM plus every output buffer a round trip needs."""
+
+    def __init__(self, z, ctx, torch, dev, nb, size, capmul=1.125):
+        self.z, self.ctx, self.torch, self.nb, self.size = z, ctx, torch, nb, size
+        self.cap = int(size * capmul) + 1024
+        i64 = dict(dtype=torch.int64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.in_off = torch.arange(nb + 1, **i64) * size
+        self.out_off = torch.arange(nb + 1, **i64) * self.cap
+        self.d_out = torch.zeros(nb * self.cap, dtype=torch.uint8, device=dev)
+        self.d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
+        self.d_len, self.d_st, self.d_dlen, self.d_cons, self.d_code, self.d_first, self.d_dst = (
+            torch.zeros(nb, **i32) for _ in range(7))
+        self.enc_ms, self.dec_ms = [], []
+        self.enc_name = self.dec_name = ""
+        torch.cuda.synchronize()          # the ctx stream is non-blocking: order torch's fills before its kernels
+
+    def step(self, model, d_in, flags, record=False):
+        c = self.ctx
+        c.encode_blocks_dev(model, self.nb, d_in.data_ptr(), self.in_off.data_ptr(), flags, self.d_out.data_ptr(),
+                            self.out_off.data_ptr(), self.d_len.data_ptr(), self.d_st.data_ptr())
+        if record:
+            c.sync()
+            self.enc_ms.append(c.last_kernel_ms)       # HIP events on the ctx stream around the kernel
+            self.enc_name = c.last_kernel_name
+        c.decode_blocks_dev(model, self.nb, self.d_out.data_ptr(), self.out_off.data_ptr(), flags, self.d_dec.data_ptr(),
+                            self.in_off.data_ptr(), self.d_dlen.data_ptr(), self.d_cons.data_ptr(), self.d_code.data_ptr(),
+                            self.d_first.data_ptr(), self.d_dst.data_ptr())
+        if record:
+            c.sync()
+            self.dec_ms.append(c.last_kernel_ms)
+            self.dec_name = c.last_kernel_name
+
+    def ok(self, d_in):
+        t = self.torch
+        return bool((self.d_st == 0).all()) and bool((self.d_dst == 0).all()) and bool((self.d_dlen == self.size).all()) \
+            and bool(t.equal(self.d_dec, d_in)) and bool((self.d_first == 0).all())
+
+    def coded_bytes(self):
+        return float(self.d_len.sum().item())
+
+
+def roofline_of(A_minus_r, ratio, nb, size, enc_ms, dec_ms, names):
+    A = A_minus_r + ratio
+    dom_ms, dom = (dec_ms, names[1]) if dec_ms >= enc_ms else (enc_ms, names[0])
+    achieved = A * nb * size / (dom_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_input_byte": round(A, 3),
+            "encode_frac": round(A * nb * size / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "decode_frac": round(A * nb * size / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    for f in ("zpq_chain.hip", "zpq_common.h", "zpq_vm.h"):
+        h.update(open(os.path.join(ROOT, "zpaq-v_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(dom_name, nb):
+    """HBM bytes per launch of the dominant kernel from the round's rocprofv3 --pmc passes
+    (profiles/r02_pmc.json, written by tools/pmc_collect.py).  Only reported when that profile was
+    taken on exactly the kernel source this run executes; otherwise null, with the reason."""
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not os.path.exists(pmc):
+        return None, "no PMC profile for this round yet"
+    try:
+        pj = json.load(open(pmc))
+        if pj.get("_kernel_src_sha") != kernel_src_sha():
+            return None, "profiles/r02_pmc.json was taken on another kernel source (%s)" % pj.get("_kernel_src_sha")
+        t = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
+        if t is None:
+            return None, "kernel not in profile"
+        return int(t * nb / pj.get("_blocks_per_launch", nb)), "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes, %s" % pj.get("_note", "")
+    except Exception as e:                                      # noqa: BLE001
+        return None, "profile unreadable: %r" % (e,)
 
 
 def main():
@@ -63,9 +183,13 @@ def main():
     ap.add_argument("--level", type=int, default=2)
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip per_class / value_incl_pcie / secondary (N=1 extras)")
+    ap.add_argument("--cpu-blocks-per-thread", type=int, default=128)
+    ap.add_argument("--cpu-one-thread-blocks", type=int, default=48)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--state-budget-gib", type=float, default=0.0, help="cap the per-ctx state pool (rehearsals sharing one GPU)")
     a = ap.parse_args()
 
     import numpy as np
@@ -92,6 +216,8 @@ def main():
     z = ge.load()
     from zpaq_v_amd.sharding import shard_indices
     ctx = z.Context(local_rank)
+    if a.state_budget_gib > 0:
+        z.lib().zpq_ctx_set_state_budget(ctx.h, int(a.state_budget_gib * (1 << 30)))
     model = z.Model(level=a.level)
     nb, size = a.blocks, a.size
     total_blocks = nb * world
@@ -109,17 +235,8 @@ def main():
         else:
             host[i] = W.make_block(b, size)
     d_in = torch.from_numpy(host.reshape(-1)).to(dev)
-    cap = size + size // 8 + 1024
-    i64 = dict(dtype=torch.int64, device=dev)
-    i32 = dict(dtype=torch.int32, device=dev)
-    in_off = torch.arange(nb + 1, **i64) * size
-    out_off = torch.arange(nb + 1, **i64) * cap
-    dec_off = torch.arange(nb + 1, **i64) * size
-    d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
-    d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
-    d_len, d_st = torch.zeros(nb, **i32), torch.zeros(nb, **i32)
-    d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(5))
     flags = z.FLAG_PP
+    rb = ResidentBatch(z, ctx, torch, dev, nb, size)
 
     def sync():
         ctx.sync()
@@ -127,36 +244,20 @@ def main():
         if world > 1:
             dist.barrier()
 
-    enc_ms, dec_ms = [], []
-
-    def step(record):
-        ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), flags, d_out.data_ptr(),
-                              out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
-        if record:
-            ctx.sync()
-            enc_ms.append(ctx.last_kernel_ms)      # HIP events on the ctx stream around the kernel
-        ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), flags, d_dec.data_ptr(),
-                              dec_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
-                              d_first.data_ptr(), d_dst.data_ptr())
-        if record:
-            ctx.sync()
-            dec_ms.append(ctx.last_kernel_ms)
-
     for _ in range(a.warmup):
-        step(False)
+        rb.step(model, d_in, flags)
     sync()
     t0 = time.time()
     for _ in range(a.steps):
-        step(False)
+        rb.step(model, d_in, flags)
     sync()
     dt = time.time() - t0
     # separate, untimed pass for per-kernel durations (event queries would add host syncs to the timed region)
-    step(True)
+    rb.step(model, d_in, flags, record=True)
     sync()
 
-    ok = bool((d_st == 0).all()) and bool((d_dst == 0).all()) and bool((d_dlen == size).all()) \
-        and bool(torch.equal(d_dec, d_in)) and bool((d_first == 0).all())
-    coded_bytes = float(d_len.sum().item())
+    ok = rb.ok(d_in)
+    coded_bytes = rb.coded_bytes()
     rdev = dev if a.backend == "nccl" else torch.device("cpu")   # the only cross-rank traffic: two tiny reductions
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     stats = torch.tensor([coded_bytes, 1.0 if ok else 0.0], dtype=torch.float64, device=rdev)
@@ -166,52 +267,133 @@ def main():
     dt = float(tmax.item())
     all_ok = stats[1].item() == world
 
+    res = None
     if rank == 0:
         B_total = total_blocks * size
         ms_per_step = dt / a.steps * 1e3
         value = B_total / (dt / a.steps) / 1e6
         ratio = stats[0].item() / B_total
-        A = ALG_BYTES_PER_INPUT_BYTE_L.get(a.level, 195) + ratio
-        dom_ms, dom_name = (dec_ms[-1], "k_chain<decode>") if dec_ms[-1] >= enc_ms[-1] else (enc_ms[-1], "k_chain<encode>")
-        # PMC traffic was collected at 4096 blocks per launch; scale to this launch size
-        pmc_blocks = 4096
-        launch_bytes = A * nb * size                          # algorithmic bytes one launch moves
-        achieved = launch_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
-                pmc_blocks = pj.get("_blocks_per_launch", 4096)
-                if traffic is not None:
-                    traffic = int(traffic * nb / pmc_blocks)
-            except Exception:
-                traffic = None
+        enc_ms, dec_ms = rb.enc_ms[-1], rb.dec_ms[-1]
+        roof = roofline_of(ALG_BYTES_PER_INPUT_BYTE_L.get(a.level, 195), ratio, nb, size, enc_ms, dec_ms,
+                           ("k_chain<encode>", "k_chain<decode>"))
+        traffic, tnote = measured_traffic(roof["kernel"], nb)
+        roof["traffic"] = traffic
+        roof["traffic_source"] = tnote
+        roof["cycles_per_coded_bit_at_2.4GHz"] = round(max(enc_ms, dec_ms) * 1e-3 * 2.4e9 / ((size + 1) * 8), 1)
         res = {
             "metric": "MB/s (comp+decomp) on level-2 64KiB blocks", "value": round(value, 2), "unit": "MB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "level %d (ICM16+ISSE16+ISSE16), %d x %d B blocks per GPU%s, one segment per "
+            "config": {"workload": "level %d (%s), %d x %d B blocks per GPU%s, one segment per "
                                    "block, classes b mod 4 = zeros/uniform/markov-text/periodic (text blocks drawn "
                                    "from 64 distinct generated blocks)" % (
-                                       a.level, nb, size,
+                                       a.level, LEVEL_NAMES.get(a.level, "?"), nb, size,
                                        " (C5's per-GPU share of 65536 blocks over 8 GPUs)" if nb == 8192 else ""),
                        "blocks_per_gpu": nb, "block_bytes": size, "level": a.level,
                        "parallelism": "block b -> gpu b mod %d, no collective" % world},
             "roundtrip_bit_exact": all_ok, "ratio": round(ratio, 4),
-            "comp_MBps": round(nb * size / (enc_ms[-1] * 1e-3) / 1e6, 1),
-            "decomp_MBps": round(nb * size / (dec_ms[-1] * 1e-3) / 1e6, 1),
-            "kernel_ms": {"k_chain<encode>": round(enc_ms[-1], 3), "k_chain<decode>": round(dec_ms[-1], 3)},
+            "coded_bytes": int(stats[0].item()),
+            "comp_MBps": round(nb * size / (enc_ms * 1e-3) / 1e6, 1),
+            "decomp_MBps": round(nb * size / (dec_ms * 1e-3) / 1e6, 1),
+            "kernel_ms": {"k_chain<encode>": round(enc_ms, 3), "k_chain<decode>": round(dec_ms, 3)},
             "resident_blocks": ctx.last_slots,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_input_byte": round(A, 3),
-                         "cycles_per_coded_bit_at_2.4GHz": round(dom_ms * 1e-3 * 2.4e9 / ((size + 1) * 8), 1)},
+            "roofline": roof,
         }
-        if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.level, size)
+
+    if rank == 0 and world == 1 and not a.no_secondary:
+        # ---- per class: the headline workload, one block class at a time (each class's blocks of the headline
+        #      batch repeated to the same launch size, so residency and launch shape are the headline's)
+        per_class = {}
+        names = ["zeros", "uniform", "markov_text", "periodic"]
+        for cls in range(4):
+            idx = torch.arange(cls, nb, 4, device=dev)
+            reps = (nb + idx.numel() - 1) // idx.numel()
+            sel = idx.repeat(reps)[:nb]
+            d_cls = d_in.view(nb, size).index_select(0, sel).reshape(-1).contiguous()
+            torch.cuda.synchronize()
+            rb.enc_ms.clear(); rb.dec_ms.clear()
+            rb.step(model, d_cls, flags)
+            rb.step(model, d_cls, flags, record=True)
+            okc = rb.ok(d_cls)
+            e, d = rb.enc_ms[-1], rb.dec_ms[-1]
+            per_class[names[cls]] = {"comp_MBps": round(nb * size / e / 1e3, 1), "decomp_MBps": round(nb * size / d / 1e3, 1),
+                                     "roundtrip_MBps": round(nb * size / (e + d) / 1e3, 1),
+                                     "ratio": round(rb.coded_bytes() / (nb * size), 4), "roundtrip_bit_exact": okc}
+            del d_cls
+        res["per_class"] = per_class
+        cap = rb.cap
+        del rb
+        torch.cuda.empty_cache()
+
+        # ---- PCIe-inclusive: the same batch through the host-pointer entry points (what a V front end
+        #      holding host buffers calls): H2D + kernel + D2H inside each call
+        L = z.lib()
+        in_off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(size)
+        out_off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(cap)
+        src = np.ascontiguousarray(host.reshape(-1))
+        out = np.zeros(nb * cap, dtype=np.uint8)
+        dec = np.zeros(nb * size, dtype=np.uint8)
+        olen = np.zeros(nb, dtype=np.uint32); st = np.zeros(nb, dtype=np.int32)
+        dlen = np.zeros(nb, dtype=np.uint32); dst = np.zeros(nb, dtype=np.int32)
+        pc = {}
+        for rep in range(2):
+            t0 = time.time()
+            rc1 = L.zpq_encode_blocks(ctx.h, model.h, nb, src.ctypes.data, in_off.ctypes.data, flags, out.ctypes.data,
+                                      out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
+            t1 = time.time()
+            rc2 = L.zpq_decode_blocks(ctx.h, model.h, nb, out.ctypes.data, out_off.ctypes.data, flags, dec.ctypes.data,
+                                      in_off.ctypes.data, dlen.ctypes.data, None, None, None, dst.ctypes.data)
+            t2 = time.time()
+            pc = {"value": round(nb * size / (t2 - t0) / 1e6, 1), "unit": "MB/s",
+                  "comp_MBps": round(nb * size / (t1 - t0) / 1e6, 1), "decomp_MBps": round(nb * size / (t2 - t1) / 1e6, 1),
+                  "ok": bool(rc1 == 0 and rc2 == 0 and (st == 0).all() and (dst == 0).all() and np.array_equal(dec, src)),
+                  "what": "zpq_encode_blocks + zpq_decode_blocks on host buffers (pageable numpy arrays), second of two calls"}
+        res["value_incl_pcie"] = pc["value"]
+        res["incl_pcie"] = pc
+        res["incl_pcie"]["fraction_of_device_resident"] = round(pc["value"] / res["value"], 4)
+        del out, dec
+
+        # ---- secondary configs, device-resident like the headline
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from inputs import C4B
+        secondary = {}
+
+        def run_cfg(key, what, mdl, want_nb, A_minus_r, capmul, names_):
+            cap_res = ctx.resident_capacity(mdl, flags)
+            n = min(want_nb, cap_res) if want_nb else cap_res
+            arr = host[:n] if n <= nb else np.concatenate([host] * ((n + nb - 1) // nb))[:n]
+            d = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1)).to(dev)
+            b = ResidentBatch(z, ctx, torch, dev, n, size, capmul)
+            b.step(mdl, d, flags, record=True)
+            b.step(mdl, d, flags, record=True)
+            e, dd = min(b.enc_ms), min(b.dec_ms)
+            r = b.coded_bytes() / (n * size)
+            secondary[key] = {
+                "workload": what, "blocks": n, "resident_blocks": ctx.last_slots, "resident_capacity": cap_res,
+                "comp_MBps": round(n * size / e / 1e3, 1), "decomp_MBps": round(n * size / dd / 1e3, 1),
+                "roundtrip_MBps": round(n * size / (e + dd) / 1e3, 1), "ratio": round(r, 4),
+                "kernel_ms": {b.enc_name: round(e, 2), b.dec_name: round(dd, 2)},
+                "roundtrip_bit_exact": b.ok(d),
+                "roofline": roofline_of(A_minus_r, r, n, size, e, dd, (b.enc_name, b.dec_name))}
+            del b, d
+            torch.cuda.empty_cache()
+
+        run_cfg("C2_level1", "level 1 (%s, levels.v:53-92), 4096 x 64 KiB" % LEVEL_NAMES[1], z.Model(level=1), 4096,
+                ALG_BYTES_PER_INPUT_BYTE_L[1], 1.125, None)
+        run_cfg("level3", "level 3 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[3], z.Model(level=3), 0,
+                ALG_BYTES_PER_INPUT_BYTE_L[3], 1.125, None)
+        run_cfg("level4", "level 4 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[4], z.Model(level=4), 0,
+                ALG_BYTES_PER_INPUT_BYTE_L[4], 1.125, None)
+        run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
+                z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None)
+        run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 4096 x 64 KiB",
+                z.Model(header=C4B), 4096, ALG_BYTES_C4B, 6.0, None)
+        res["secondary"] = secondary
+
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.level, size, a.cpu_blocks_per_thread, a.cpu_one_thread_blocks)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

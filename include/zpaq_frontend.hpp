@@ -127,6 +127,7 @@ private:
     bool pp_coded_;                    // compress() ran at least once: PP byte goes first (:271-274)
     std::vector<uint8_t> store_buf_;
     bool first_byte_;
+    int segs_in_block_;                // segments coded in the open block (the first one may be retried, see end_segment)
     int err_;
 };
 
@@ -145,6 +146,7 @@ public:
     void read_segment_end();                                       // :590-635
     std::vector<uint8_t> get_sha1() { return sha1_.result(); }
     int last_error() const { return err_; }
+    size_t position() const { return pos_; }                       // bytes of the input stream consumed so far
     // digest stored behind marker 253 of the segment just ended (the reference reads and drops it, :608-628)
     bool stored_sha1(uint8_t out20[20]) const { if (has_stored_sha1_) for (int i = 0; i < 20; i++) out20[i] = stored_sha1_[i]; return has_stored_sha1_; }
 private:

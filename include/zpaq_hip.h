@@ -81,6 +81,10 @@ int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
 int zpq_ctx_set_max_block_bytes(zpq_ctx *, uint64_t bytes);
 /* Resident blocks (state slots) the last batch call used; for reporting. */
 int zpq_ctx_last_slots(const zpq_ctx *);
+/* How many blocks of this model a single launch keeps resident on this ctx (the smaller of what
+ * the CUs' LDS/wave slots hold and what the state budget holds); a larger batch is worked off by
+ * the resident groups in turn.  flags as for the batch calls (kernel choice).  < 0 = ZPQ_E_*. */
+int zpq_ctx_resident_capacity(zpq_ctx *, const zpq_model *, uint32_t flags);
 /* Time of the last batch's coding kernel alone, from HIP events on the ctx stream (ms). */
 float zpq_ctx_last_kernel_ms(const zpq_ctx *);
 const char *zpq_ctx_last_kernel_name(const zpq_ctx *);
@@ -116,7 +120,16 @@ int zpq_decode_blocks(zpq_ctx *, const zpq_model *, int nblocks, const uint8_t *
                       uint32_t *final_code, uint32_t *first_byte, int32_t *status);
 
 /* Same, but every pointer is a DEVICE pointer and the call only enqueues work on
- * the ctx stream (no host sync, no PCIe).  This is the form bench.py times. */
+ * the ctx stream (no host sync, no PCIe).  This is the form bench.py times.
+ * Ordering contract: the ctx stream is created hipStreamNonBlocking, so it does NOT
+ * synchronise with the legacy default stream (or with torch's current stream).  The caller
+ * must make sure the producers of in/in_off/out_off have finished (device or stream
+ * synchronize, or an event the ctx stream waits on) before calling, and must zpq_ctx_sync()
+ * (or wait on zpq_ctx_stream()) before consuming the results on another stream.
+ * Threading contract: the host-pointer entry points (zpq_encode_blocks, zpq_decode_blocks,
+ * zpq_sha1_blocks, zpq_block_*) serialise on a per-ctx mutex and may be called from several
+ * threads; the _dev forms take no lock -- one thread per ctx at a time (they share the ctx's
+ * slot pool and stream), which is how the one-thread-per-device design of SURVEY 8(e) uses them. */
 int zpq_encode_blocks_dev(zpq_ctx *, const zpq_model *, int nblocks, const uint8_t *in,
                           const uint64_t *in_off, uint32_t flags, uint8_t *out,
                           const uint64_t *out_off, uint32_t *out_len, int32_t *status);

@@ -20,10 +20,11 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(ODIR, "libzpaq_oracle.so")
+    # ZPQ_ORACLE_SO: another build of the same source (the sanitizer build, tests/test_oracle_sanitizers.py)
+    so = os.path.join(ODIR, os.environ.get("ZPQ_ORACLE_SO", "libzpaq_oracle.so"))
     src = os.path.join(ODIR, "zpaq_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ODIR, "-s"])
+        subprocess.check_call(["make", "-C", ODIR, "-s"] + (["asan"] if "asan" in os.path.basename(so) else []))
     L = C.CDLL(so)
     vp, sz, i64, u8p = C.c_void_p, C.c_size_t, C.c_int64, C.c_char_p
     L.zo_tables.argtypes = [vp] * 5

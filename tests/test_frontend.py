@@ -220,3 +220,28 @@ def test_start_block_hcomp_quirk(zpq, gpu_ctx):
     out = comp.output_bytes()
     coded = O.Codec(hdr, (0, 0, 0)).encode(b"quirk data " * 20)
     assert out == b"\x01q\x00\x00\x00" + coded + bytes(4) + b"\xfd" + hashlib.sha1(b"quirk data " * 20).digest() + b"\xff"
+
+
+@pytest.mark.gpu
+def test_decompresser_on_archive_larger_than_64_mib(zpq, gpu_ctx):
+    """the sequential Decompresser handed the whole rest of the archive to the coder and sized
+    its output buffer at 64x that, so a modelled segment followed by more than ~64 MiB of archive failed with
+    ZPQ_E_ARG (the reference streams, decompressor.v:443-515, and has no such limit).  The segment's input is now
+    bounded by the next block locator and the output buffer grows on demand."""
+    rnd = random.Random(2)
+    head = bytes(rnd.choice(b"zpaq on mi355x\n") for _ in range(5000))
+    tail = b"the end " * 300
+    big = bytes(rnd.getrandbits(8) for _ in range(1 << 16)) * 1100          # 68.75 MiB, stored (level 0)
+    comp = zpq.Compressor(gpu_ctx)
+    add_file(comp, 2, "head.txt", head)
+    add_file(comp, 0, "big.bin", big)
+    add_file(comp, 1, "tail.txt", tail)
+    arc = comp.output_bytes()
+    assert comp.last_error == 0 and len(arc) > (68 << 20)
+    assert arc.startswith(oracle_archive(2, "head.txt", "%d bytes" % len(head), head))
+    assert arc.endswith(oracle_archive(1, "tail.txt", "%d bytes" % len(tail), tail))
+    got = extract_all(zpq, gpu_ctx, arc)
+    assert [(n, len(o)) for n, _, o, _ in got] == [("head.txt", len(head)), ("big.bin", len(big)), ("tail.txt", len(tail))]
+    assert got[0][2] == head and got[2][2] == tail and hashlib.sha1(got[1][2]).digest() == hashlib.sha1(big).digest()
+    for (_, _, o, sha) in got:
+        assert sha == hashlib.sha1(o).digest()

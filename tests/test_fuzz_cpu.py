@@ -112,3 +112,48 @@ def test_cli_filters_match_the_reference_known_answers():
            ("file.doc", ["*.txt"], ["temp*"], False)]
     for name, only, nots, want in inc:
         assert include(name, only, nots) == want, (name, only, nots)
+
+
+def test_store_mode_archive_inside_a_store_mode_archive(zpq):
+    """an archive added with -m0 keeps its locators verbatim inside the outer block's
+    payload.  The reference's sequential Decompresser consumes a block before it searches for the next one
+    (cmd/main.v:342-380, decompressor.v:518-587), so the inner archive is one ordinary member -- not extra
+    top-level files, and not a truncated outer member."""
+    inner_files = [("b.bin", "300 bytes", bytes(range(256)) + bytes(44)), ("a.txt", "11 bytes", b"hello world")]
+    inner = zpq.archive_add(None, 0, inner_files)
+    outer_files = [("in1", "5 bytes", b"first"), ("inner.zpaq", "%d bytes" % len(inner), inner), ("tail", "4 bytes", b"last")]
+    outer = zpq.archive_add(None, 0, outer_files)
+    got = zpq.archive_extract(None, outer)
+    assert [(g["name"], g["data"], g["status"], g["sha1_ok"]) for g in got] == [(f[0], f[2], 0, True) for f in outer_files]
+    # and the member really is the inner archive
+    assert [(g["name"], g["data"]) for g in zpq.archive_extract(None, got[1]["data"])] == [(f[0], f[2]) for f in inner_files]
+    # an inner archive that starts with a bare "zPQ" (no 13-byte locator), stored at the very start of a chunk
+    bare = inner[13:]
+    assert bare[:3] == b"zPQ" and [g["name"] for g in zpq.archive_extract(None, bare)] == ["b.bin", "a.txt"]
+    outer2 = zpq.archive_add(None, 0, [("bare.zpaq", "", bare), ("z", "", b"zPQ")])
+    assert [(g["name"], g["data"]) for g in zpq.archive_extract(None, outer2)] == [("bare.zpaq", bare), ("z", b"zPQ")]
+    # two archives concatenated, the second without its locator: the reader's rolling hashes restart at every
+    # find_block, so a bare "zPQ" right behind a block end is a block (decompressor.v:227-241)
+    cat = outer + bare
+    assert [g["name"] for g in zpq.archive_extract(None, cat)] == ["in1", "inner.zpaq", "tail", "b.bin", "a.txt"]
+    # a store segment cut off inside a chunk, or without its 253/254 trailer, is not reported as OK
+    cut = zpq.archive_extract(None, outer[:outer.index(b"hello world") + 3])     # inside inner.zpaq's chunk
+    assert [g["name"] for g in cut] == ["in1", "inner.zpaq"] and cut[0]["status"] == 0 and cut[1]["status"] != 0
+    notrailer = bytearray(outer)
+    k = outer.index(b"first") + 5 + 4                     # in1's trailer byte (behind the zero length)
+    assert notrailer[k] == 253
+    notrailer[k] = 7
+    assert zpq.archive_extract(None, bytes(notrailer))[0]["status"] != 0
+
+
+def test_model_create_rejects_offsets_outside_the_header(zpq):
+    """cend/hbegin/hend index the header on host and device; out-of-range values are
+    refused (ZPQ_E_HEADER beyond the header, ZPQ_E_ARG when negative), hend < hbegin is an empty program."""
+    h = zpq.level_header(2)
+    cend, hbegin, hend = zpq.scan_header(h)
+    for bad in ((len(h) + 1, hbegin, hend), (cend, len(h) + 5, hend), (cend, hbegin, len(h) + 1), (-1, hbegin, hend), (cend, -3, hend)):
+        with pytest.raises(zpq.ZpqError) as e:
+            zpq.Model(header=h, offsets=bad)
+        assert e.value.code == (-2 if min(bad) < 0 else -3)
+    m = zpq.Model(header=h, offsets=(cend, hbegin, hbegin - 4))     # empty program: accepted
+    assert m.ncomp == 3

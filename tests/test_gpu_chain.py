@@ -156,6 +156,7 @@ def test_chain_full_size_batch_properties(zpq, gpu_ctx):
     d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
     d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
     d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    torch.cuda.synchronize()                             # the _dev forms run on the ctx's own non-blocking stream
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
@@ -320,6 +321,7 @@ def _device_round_trip(zpq, ctx, model, arr, capmul, flags=None):
     d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
     d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
     d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    torch.cuda.synchronize()                             # order torch's fills before the ctx stream's kernels
     ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), flags, d_out.data_ptr(),
                           out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), flags, d_dec.data_ptr(),
@@ -332,15 +334,19 @@ def _device_round_trip(zpq, ctx, model, arr, capmul, flags=None):
     return d_out.cpu().numpy(), d_len.cpu().numpy(), cap
 
 
-@pytest.mark.parametrize("level,nb", [(1, 2048), (3, 1024), (4, 512)])
+@pytest.mark.parametrize("level,nb", [(1, 4096), (3, 1024), (4, 512)])
 def test_other_levels_at_baseline_block_size(zpq, gpu_ctx, level, nb):
     """64 KiB blocks of all four classes at the levels the headline test does not cover: round-trip
-    properties on every block, byte parity with the oracle on a sample."""
+    properties on every block, byte parity with the oracle on a sample.  Level 1 runs at C2's stated
+    size (BASELINE.json configs[1]: 4096 x 64 KiB, levels.v:53-92), all blocks resident at once -- the
+    launch shape that config ships (16 blocks per workgroup, two waves)."""
     arr = W.make_blocks_fast(nb, 65536)
     model = zpq.Model(level=level)
     out, lens, cap = _device_round_trip(zpq, gpu_ctx, model, arr, 1.125)
     assert gpu_ctx.last_kernel_name == "k_chain<decode>"
-    sample = [0, 1, 2, 3, nb // 2 + 1, nb - 2]
+    if level == 1:
+        assert gpu_ctx.last_slots == nb                  # C2: every block has its own 36 MiB slot
+    sample = [0, 1, 2, 3, nb // 2 + 1, nb - 2] + ([5, 1026, 2051, 3000, 4093, 4095] if level == 1 else [])
     want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
     for i, w in zip(sample, want):
         assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i

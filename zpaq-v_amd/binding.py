@@ -51,6 +51,7 @@ def lib():
     L.zpq_ctx_stream.restype = vp
     L.zpq_ctx_set_state_budget.argtypes = [vp, u64]
     L.zpq_ctx_last_slots.argtypes = [vp]
+    L.zpq_ctx_resident_capacity.argtypes = [vp, vp, u32]
     L.zpq_ctx_last_kernel_ms.argtypes = [vp]
     L.zpq_ctx_last_kernel_ms.restype = C.c_float
     L.zpq_ctx_last_kernel_name.argtypes = [vp]
@@ -175,6 +176,13 @@ class Context:
     @property
     def last_slots(self):
         return lib().zpq_ctx_last_slots(self.h)
+
+    def resident_capacity(self, model, flags=FLAG_PP):
+        """Blocks of `model` one launch keeps resident on this GPU (zpq_ctx_resident_capacity)."""
+        n = lib().zpq_ctx_resident_capacity(self.h, model.h, flags)
+        if n < 0:
+            raise ZpqError(n, "zpq_ctx_resident_capacity")
+        return n
 
     def encode_blocks(self, model, blocks, flags=FLAG_PP, cap=None):
         nb = len(blocks)

@@ -57,10 +57,22 @@ struct DevBuf {
     int ensure(size_t n)
     {
         if (n <= cap) return ZPQ_OK;
+        // Grow: take the new buffer first so that a failed regrow keeps the old one usable.  Pools of ~100 GiB
+        // cannot coexist with their successor; only then is the old one given up before the second attempt.
+        size_t want = n + n / 8 + 4096;
+        void *q = nullptr;
+        if (hipMalloc(&q, want) != hipSuccess) {
+            (void)hipGetLastError();
+            q = nullptr;
+            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+            if (hipMalloc(&q, want) != hipSuccess) {
+                (void)hipGetLastError();
+                want = n + 4096;
+                if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return ZPQ_E_NOMEM; }
+            }
+        }
         if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        const size_t want = n + n / 8 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ZPQ_E_NOMEM; }
+        p = q;
         cap = want;
         return ZPQ_OK;
     }
@@ -102,6 +114,7 @@ struct zpq_block {
 };
 
 // ------------------------------------------------------------------ ctx
+static int ctx_init(zpq_ctx *c, const zpq::Tables &T);
 extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
 {
     if (!out) return ZPQ_E_ARG;
@@ -116,6 +129,15 @@ extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
     zpq_ctx *c = new (std::nothrow) zpq_ctx();
     if (!c) return ZPQ_E_NOMEM;
     c->device = device;
+    const int rc = ctx_init(c, T);
+    if (rc != ZPQ_OK) { zpq_ctx_destroy(c); return rc; }   // releases whatever the failed step left behind
+    *out = c;
+    return ZPQ_OK;
+}
+
+static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
+{
+    const int device = c->device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount;
     HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -141,7 +163,6 @@ extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->budget = (uint64_t)fr / 4 * 3;
     else c->budget = 64ull << 30;
-    *out = c;
     return ZPQ_OK;
 }
 
@@ -226,29 +247,81 @@ struct BatchArgs {
     uint8_t *own_slot;   // zpq_block: use this slot instead of the pool
 };
 
+// What a batch call will launch: kernel family, slot layout, resident slots and grid.
+struct Plan {
+    bool chain = false, lanes = false;
+    int sp = 0;                  // compact line store capacity (log2 lines), 0 = dense tables
+    const DModel *M = nullptr;   // layout the kernels see (dense or compact)
+    int nslots = 0, grid = 0, bpw = 0;
+};
+
+static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P)
+{
+    P->chain = m->d.fast_kind && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
+               !trace && !own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
+    // chain kernel + huge hash tables (levels 4-5): compact line store layout of the slot
+    static thread_local DModel sparse_layout;
+    P->sp = 0;
+    if (P->chain) {
+        const char *ev = getenv("ZPQ_SPARSE_FORCE_LOG2");        // tests: exercise the store on small models
+        const int cap = ev ? atoi(ev) : c->sparse_log2;
+        if (cap >= 8 && cap <= 26 && zpq_sparse_layout(m->d, cap, &sparse_layout)) P->sp = cap;
+    }
+    P->M = P->sp ? &sparse_layout : &m->d;
+    const DModel &M = *P->M;
+    // everything else with up to 64 components: one block per wave, lane i = component i
+    P->lanes = !P->chain && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY | ZB_KEEP_STATE)) &&
+               !trace && !own_slot && zpq_lanes_supported(&m->d);
+    const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)nblocks;
+    if (max_by_mem == 0 && !own_slot) return ZPQ_E_NOMEM;
+    int nslots, grid, bpw = 0;
+    if (P->chain) {
+        const uint64_t can_hold = max_by_mem < (uint64_t)nblocks ? max_by_mem : (uint64_t)nblocks;
+        if (!zpq_chain_plan(&M, (int)can_hold, c->cus, &bpw)) return ZPQ_E_INTERNAL;
+        int nwg = (nblocks + bpw - 1) / bpw;
+        const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
+        if (nwg > cap_wg) nwg = cap_wg;
+        nslots = nwg * bpw;
+        if ((uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;      // last workgroup partly idle
+        if (nslots > nblocks) nslots = nblocks;
+        nwg = (nslots + bpw - 1) / bpw;
+        grid = nwg;
+    } else {
+        nslots = nblocks;
+        const int cap_res = c->cus * (P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
+        if (nslots > cap_res) nslots = cap_res;
+        if (!own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
+        grid = nslots;
+    }
+    if (own_slot) { nslots = 1; grid = 1; }
+    P->nslots = nslots; P->grid = grid; P->bpw = bpw;
+    return ZPQ_OK;
+}
+
+extern "C" int zpq_ctx_resident_capacity(zpq_ctx *c, const zpq_model *m, uint32_t flags)
+{
+    if (!c || !m) return ZPQ_E_ARG;
+    Plan P;
+    const int rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &P);
+    return rc != ZPQ_OK ? rc : P.nslots;
+}
+
 static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs &a)
 {
     if (!c || !m) return ZPQ_E_ARG;
     if (a.nblocks < 0) return ZPQ_E_ARG;
     if (a.nblocks == 0) return ZPQ_OK;
     if (!a.in_off || !a.out_off || !a.out_len || !a.status) return ZPQ_E_ARG;
+    if (a.own_slot && a.nblocks != 1) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
-    const bool want_chain = m->d.fast_kind && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
-                            !a.trace && !a.own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
-    // chain kernel + huge hash tables (levels 4-5): compact line store layout of the slot
-    static thread_local DModel sparse_layout;
-    int sp = 0;
-    if (want_chain) {
-        const char *ev = getenv("ZPQ_SPARSE_FORCE_LOG2");        // tests: exercise the store on small models
-        const int cap = ev ? atoi(ev) : c->sparse_log2;
-        if (cap >= 8 && cap <= 26 && zpq_sparse_layout(m->d, cap, &sparse_layout)) sp = cap;
-    }
-    const DModel &M = sp ? sparse_layout : m->d;
-    // everything else with up to 64 components: one block per wave, lane i = component i
-    const bool want_lanes = !want_chain && !(a.flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY | ZB_KEEP_STATE)) &&
-                            !a.trace && !a.own_slot && zpq_lanes_supported(&m->d);
+    Plan P;
+    int rc = plan_batch(c, m, a.flags, a.nblocks, a.trace != nullptr, a.own_slot != nullptr, &P);
+    if (rc != ZPQ_OK) return rc;
+    const DModel &M = *P.M;
+    const bool want_chain = P.chain, want_lanes = P.lanes;
+    const int nslots = P.nslots, grid = P.grid, bpw = P.bpw;
     DevModel dm;
-    int rc = get_dev_model(c, m, M, sp, &dm);
+    rc = get_dev_model(c, m, M, P.sp, &dm);
     if (rc != ZPQ_OK) return rc;
 
     DBatch B;
@@ -261,30 +334,8 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     B.squash = c->d_squash; B.stretch = c->d_stretch; B.dt = c->d_dt; B.dt2k = c->d_dt2k;
     B.ns = c->d_ns; B.stretch_c = c->d_stretch_c;
 
-    const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)a.nblocks;
-    if (max_by_mem == 0 && !a.own_slot) return ZPQ_E_NOMEM;
-    int nslots, grid, bpw = 0;
-    if (want_chain) {
-        const uint64_t can_hold = max_by_mem < (uint64_t)a.nblocks ? max_by_mem : (uint64_t)a.nblocks;
-        if (!zpq_chain_plan(&M, (int)can_hold, c->cus, &bpw)) return ZPQ_E_INTERNAL;
-        int nwg = (a.nblocks + bpw - 1) / bpw;
-        const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
-        if (nwg > cap_wg) nwg = cap_wg;
-        nslots = nwg * bpw;
-        if ((uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;      // last workgroup partly idle
-        if (nslots > a.nblocks) nslots = a.nblocks;
-        nwg = (nslots + bpw - 1) / bpw;
-        grid = nwg;
-    } else {
-        nslots = a.nblocks;
-        const int cap_res = c->cus * (want_lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
-        if (nslots > cap_res) nslots = cap_res;
-        if (!a.own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
-        grid = nslots;
-    }
     if (a.own_slot) {
-        if (a.nblocks != 1) return ZPQ_E_ARG;
-        B.slots = a.own_slot; nslots = 1; grid = 1;
+        B.slots = a.own_slot;
     } else {
         rc = c->slots.ensure((size_t)nslots * M.slot_bytes);
         if (rc != ZPQ_OK) return rc;
@@ -384,7 +435,12 @@ static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, c
     if (decode && consumed) HIPCK(hipMemcpyAsync(consumed, a.consumed, u32b, hipMemcpyDeviceToHost, s));
     if (decode && final_code) HIPCK(hipMemcpyAsync(final_code, a.final_code, u32b, hipMemcpyDeviceToHost, s));
     if (decode && first_byte) HIPCK(hipMemcpyAsync(first_byte, a.first_byte, u32b, hipMemcpyDeviceToHost, s));
-    if (out_bytes) HIPCK(hipMemcpyAsync(out, c->s_out.p, out_bytes, hipMemcpyDeviceToHost, s));
+    if (out_bytes && nblocks == 1) {
+        // one segment (zpq_block_*): its slab is sized for the worst case; move only what was produced
+        HIPCK(hipStreamSynchronize(s));
+        const size_t got = out_len[0] < out_bytes ? out_len[0] : out_bytes;
+        if (got) HIPCK(hipMemcpyAsync(out, c->s_out.p, got, hipMemcpyDeviceToHost, s));
+    } else if (out_bytes) HIPCK(hipMemcpyAsync(out, c->s_out.p, out_bytes, hipMemcpyDeviceToHost, s));
     if (trace) HIPCK(hipMemcpyAsync(trace, c->s_misc.p, (size_t)ntrace * 4, hipMemcpyDeviceToHost, s));
     if (ctx_out) HIPCK(hipMemcpyAsync(ctx_out, c->s_misc.p, ctx_words * 4, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
@@ -410,7 +466,9 @@ extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, co
 
 // ------------------------------------------------------------------ slab compaction
 // out_len[b] bytes of each capacity-strided output slab -> one dense buffer, so that only real
-// payload bytes cross PCIe.  One workgroup per block, 16-byte moves once the destination is aligned.
+// payload bytes cross PCIe.  One workgroup per block: bytes up to the destination's first 16-byte
+// boundary, then 16-byte stores fed by two aligned 16-byte loads funnel-shifted to the source's
+// misalignment, then the tail.
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
                                                 uint8_t *dst, const uint64_t *dst_off, int n)
 {
@@ -419,7 +477,30 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64
     const uint8_t *s = src + src_off[b];
     uint8_t *d = dst + dst_off[b];
     const uint32_t L = len[b];
-    for (uint32_t i = threadIdx.x; i < L; i += 256) d[i] = s[i];
+    uint32_t head = (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u);
+    if (head > L) head = L;
+    for (uint32_t i = threadIdx.x; i < head; i += 256) d[i] = s[i];
+    const uint32_t nvec = (L - head) / 16u;
+    const uint8_t *sv = s + head;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(sv) & 3u);      // source byte offset inside its dword
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(sv - mis);
+    uint4 *d16 = reinterpret_cast<uint4 *>(d + head);
+    const uint32_t sh = mis * 8u;
+    for (uint32_t v = threadIdx.x; v < nvec; v += 256) {
+        const uint32_t *q = s4 + 4u * v;
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+        uint4 o;
+        if (mis == 0) { o = make_uint4(w0, w1, w2, w3); }
+        else {
+            const uint32_t w4 = q[4];                       // in bounds: mis > 0 means bytes of the 5th dword belong to this vector
+            o.x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
+            o.y = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+            o.z = (uint32_t)((((uint64_t)w3 << 32) | w2) >> sh);
+            o.w = (uint32_t)((((uint64_t)w4 << 32) | w3) >> sh);
+        }
+        d16[v] = o;
+    }
+    for (uint32_t i = head + nvec * 16u + threadIdx.x; i < L; i += 256) d[i] = s[i];
 }
 
 extern "C" int zpq_gather_dev(zpq_ctx *c, int nblocks, const uint8_t *src, const uint64_t *src_off, const uint32_t *len,

@@ -243,26 +243,58 @@ struct BlockRec {
     std::string name, comment;
     size_t payload = 0;          // first byte of the coded data of the first segment
     size_t next_tag = 0;         // start of the next block's locator window (or archive end)
+    size_t end = 0;              // store-mode blocks: where the sequential reader stands after the block (0 = not known yet)
 };
 
-// find_block (decompressor.v:219-346) on a flat buffer: false = the reference's loop would stop here
-bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b)
+// Walks a store-mode block (no components) from its first segment marker to the byte after its end-of-block
+// marker, exactly as the sequential loop consumes it: per segment `01 name 00 comment 00 00`, length-prefixed
+// chunks up to a zero length (decompressor.v:518-587), the trailer byte (+ 20 digest bytes behind 253, :590-635),
+// then the next marker; 0xFF ends the block (:350-368).  A stream that ends inside the block leaves the reader at n.
+size_t walk_store_block(const uint8_t *a, size_t n, size_t q)
+{
+    auto get = [&]() -> int { return q < n ? a[q++] : -1; };
+    for (;;) {
+        const int marker = get();                          // find_filename
+        if (marker < 0) return n;
+        if (marker == 0xFF) return q;
+        for (;;) { const int c = get(); if (c < 0) return n; if (c == 0) break; if (c == 0xFF) return q; }
+        for (;;) { const int c = get(); if (c < 0) return n; if (c == 0) break; }
+        if (get() < 0) return n;
+        for (;;) {                                         // decompress_store
+            if (n - q < 4) return n;
+            const uint32_t len = ((uint32_t)a[q] << 24) | ((uint32_t)a[q + 1] << 16) | ((uint32_t)a[q + 2] << 8) | (uint32_t)a[q + 3];
+            q += 4;
+            if (len == 0) break;
+            if (n - q < len) return n;
+            q += len;
+        }
+        const int trailer = get();                         // read_segment_end
+        if (trailer < 0) return n;
+        if (trailer == 253) { if (n - q < 20) return n; q += 20; }
+    }
+}
+
+// find_block (decompressor.v:219-346) on a flat buffer: false = the reference's loop would stop here.
+// `at_reader` says that `pos` is a position the sequential reader really stands at (stream start, or right
+// behind a block whose end is known): only there may a bare "zPQ" start a block.
+bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b, bool at_reader)
 {
     // The reference rolls four 32-bit hashes h = h*{12,20,28,44} + c over the stream and stops when all
     // four hit their targets (decompressor.v:227-241).  12^16 = 20^16 = 28^16 = 44^16 = 0 (mod 2^32), so the
     // hashes are a function of the last 16 bytes only, and the targets are the hashes of the 13-byte
     // locator + "zPQ"; the initial constants are the state after the 13 locator bytes, so a stream that
-    // starts with "zPQ" matches too.  Searching for those bytes is the same test (up to a 128-bit hash
-    // collision) at memmem speed instead of 16 multiplies per archive byte.
+    // starts with "zPQ" WHERE find_block BEGINS READING matches too.  Searching for those bytes is the same
+    // test (up to a 128-bit hash collision) at memmem speed instead of 16 multiplies per archive byte.
     static const uint8_t tag16[16] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3, 0x7a, 0x50, 0x51};
     if (pos >= n) return false;
-    if (pos + 3 <= n && memcmp(a + pos, tag16 + 13, 3) == 0) { b.tag_pos = pos; pos += 3; }
+    if (at_reader && pos + 3 <= n && memcmp(a + pos, tag16 + 13, 3) == 0) { b.tag_pos = pos; pos += 3; }
     else {
         const void *m = memmem(a + pos, n - pos, tag16, sizeof tag16);
         if (!m) { pos = n; return false; }
         b.tag_pos = (size_t)(static_cast<const uint8_t *>(m) - a);
         pos = b.tag_pos + 16;
     }
+    b.end = 0;
     auto get = [&]() -> int { return pos < n ? a[pos++] : -1; };
     const int level = get();
     if (level != 1 && level != 2) return false;
@@ -286,31 +318,42 @@ bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b)
     const int hcomp_len = hsize - (int)b.hdr.size();
     for (int i = 0; i < hcomp_len; i++) { const int v = get(); if (v < 0) return false; b.hdr.push_back((uint8_t)v); }
     b.hend = (int)b.hdr.size() - 1;
+    const size_t body = pos;
     // find_filename (decompressor.v:350-429) for the first segment
     b.has_segment = false;
     b.name.clear(); b.comment.clear();
     size_t q = pos;
     auto get2 = [&]() -> int { return q < n ? a[q++] : -1; };
-    const int marker = get2();
-    if (marker < 0 || marker == 0xFF) { pos = q; return true; }
-    for (;;) { const int c = get2(); if (c < 0) return true; if (c == 0) break; if (c == 0xFF) { pos = q; return true; } b.name.push_back((char)c); }
-    for (;;) { const int c = get2(); if (c < 0) return true; if (c == 0) break; b.comment.push_back((char)c); }
-    if (get2() < 0) return true;
-    b.has_segment = true;
-    b.payload = q;
-    pos = q;
+    auto parse_first = [&]() {
+        const int marker = get2();
+        if (marker < 0 || marker == 0xFF) { pos = q; return; }
+        for (;;) { const int c = get2(); if (c < 0) return; if (c == 0) break; if (c == 0xFF) { pos = q; return; } b.name.push_back((char)c); }
+        for (;;) { const int c = get2(); if (c < 0) return; if (c == 0) break; b.comment.push_back((char)c); }
+        if (get2() < 0) return;
+        b.has_segment = true;
+        b.payload = q;
+        pos = q;
+    };
+    parse_first();
+    if (b.ncomp == 0) {
+        // Store mode: the payload is raw bytes and may itself hold locators (an archive stored inside an
+        // archive).  The sequential reader consumes the block before it looks for the next one
+        // (cmd/main.v:342-380), so the search resumes behind it, never inside it.
+        b.end = walk_store_block(a, n, body);
+        pos = b.end;
+    }
     return true;
 }
 
-// every segment of one block through the sequential front end
-void replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool want_data, std::vector<ArchiveFile> *out)
+// every segment of one block through the sequential front end; returns how far into [from, to) the reader got
+size_t replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool want_data, std::vector<ArchiveFile> *out)
 {
     FileReader r(std::vector<uint8_t>(a + from, a + to));
     Decompresser d(ctx);
     d.set_input(&r);
     if (!d.find_block()) {
         if (d.last_error() != ZPQ_OK) { ArchiveFile f; f.status = d.last_error(); out->push_back(std::move(f)); }
-        return;
+        return from + d.position();
     }
     while (d.find_filename()) {
         ArchiveFile f;
@@ -319,9 +362,9 @@ void replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool w
         FileWriter fw;
         d.set_output(&fw);
         while (d.decompress(65536)) {}
-        f.status = d.last_error();
         const std::vector<uint8_t> digest = d.get_sha1();
         d.read_segment_end();
+        f.status = d.last_error();
         uint8_t stored[20];
         if (d.stored_sha1(stored)) f.sha1_ok = memcmp(stored, digest.data(), 20) == 0;
         f.size = fw.bytes().size();
@@ -330,6 +373,7 @@ void replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool w
         out->push_back(std::move(f));
         if (fst != ZPQ_OK) break;
     }
+    return from + d.position();
 }
 
 uint64_t size_hint(const std::string &comment)            // the CLI's "<n> bytes" comment (cmd/main.v:300-302); only a capacity hint
@@ -369,7 +413,7 @@ int archive_extract(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size
 }
 
 namespace {
-struct Decoded { bool done = false; ArchiveFile f; };
+struct Decoded { bool done = false; size_t end = 0; ArchiveFile f; };
 typedef std::map<std::vector<uint8_t>, std::vector<int>> Groups;
 }  // namespace
 static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, const std::vector<BlockRec> &blocks,
@@ -378,16 +422,23 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
 static int extract_segments(const std::vector<zpq_ctx *> &ctxs, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files)
 {
     zpq_ctx *ctx = ctxs[0];
-    // ---- pass 1: every block the sequential loop would visit
+    // ---- pass 1: every block the sequential loop could visit.  Store-mode blocks are walked to their end, so
+    //      nothing inside their raw payload is mistaken for a block; modelled blocks end where their decoder
+    //      stops, which only pass 3 knows: records that turn out to lie inside one are dropped there.
     std::vector<BlockRec> blocks;
     {
         size_t pos = 0;
+        bool at_reader = true;
         for (;;) {
             BlockRec b;
-            if (!next_block(arc, n, pos, b)) break;
+            if (!next_block(arc, n, pos, b, at_reader)) break;
+            at_reader = b.end != 0;
             blocks.push_back(std::move(b));
         }
-        for (size_t i = 0; i < blocks.size(); i++) blocks[i].next_tag = i + 1 < blocks.size() ? blocks[i + 1].tag_pos : n;
+        for (size_t i = 0; i < blocks.size(); i++) {
+            blocks[i].next_tag = i + 1 < blocks.size() ? blocks[i + 1].tag_pos : n;
+            if (blocks[i].end && blocks[i].end < blocks[i].next_tag) blocks[i].next_tag = blocks[i].end;   // replay exactly the block
+        }
     }
     // ---- pass 2: one batch per distinct header over the single-segment candidates
     std::vector<Decoded> dec(blocks.size());
@@ -409,10 +460,23 @@ static int extract_segments(const std::vector<zpq_ctx *> &ctxs, const uint8_t *a
         }
         for (int r : rcs) if (r != ZPQ_OK) return r;
     }
-    // ---- everything else, in archive order
-    for (size_t i = 0; i < blocks.size(); i++) {
-        if (dec[i].done) { files->push_back(std::move(dec[i].f)); continue; }
-        replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
+    // ---- everything else, in archive order, following the sequential reader: `seq` is where it stands.
+    //      A record that begins before `seq` lies inside the block just consumed (the reference never sees it);
+    //      a bare "zPQ" exactly at `seq` starts a block the locator search could not see.
+    static const uint8_t zpq3[3] = {0x7a, 0x50, 0x51};
+    size_t seq = 0;
+    for (size_t i = 0; i <= blocks.size(); i++) {
+        const size_t tag = i < blocks.size() ? blocks[i].tag_pos : n;
+        if (tag < seq) continue;
+        while (seq + 3 <= tag && memcmp(arc + seq, zpq3, 3) == 0 && !(i < blocks.size() && tag == seq)) {
+            const size_t stop = replay_block(ctx, arc, seq, tag, want_data, files);
+            if (stop <= seq) break;
+            seq = stop;
+        }
+        if (i == blocks.size()) break;
+        if (tag < seq) continue;                               // swallowed by a bare block just replayed
+        if (dec[i].done) { files->push_back(std::move(dec[i].f)); seq = dec[i].end; continue; }
+        seq = replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
     }
     return ZPQ_OK;
 }
@@ -531,6 +595,7 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
                     if (get() != 0xFF) continue;                                   // more segments (or damage): replay sequentially
                     Decoded &d = dec[bi];
                     d.done = true;
+                    d.end = p;
                     d.f.name = b.name;
                     d.f.comment = b.comment;
                     d.f.sha1_ok = sha_ok;

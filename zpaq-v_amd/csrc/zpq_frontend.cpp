@@ -125,13 +125,14 @@ void block_end(Writer &w) { w.put(0xFF); }                          // compresso
 
 Compressor::Compressor(zpq_ctx *ctx)
     : state_(kStart), ctx_(ctx), model_(nullptr), block_(nullptr), input_(nullptr), output_(nullptr),
-      level_(1), ncomp_(0), pp_coded_(false), first_byte_(true), err_(ZPQ_OK)
+      level_(1), ncomp_(0), pp_coded_(false), first_byte_(true), segs_in_block_(0), err_(ZPQ_OK)
 {
 }
 Compressor::~Compressor() { drop_block(); }
 
 void Compressor::drop_block()
 {
+    segs_in_block_ = 0;
     if (block_) { zpq_block_destroy(block_); block_ = nullptr; }
     if (model_) { zpq_model_destroy(model_); model_ = nullptr; }
 }
@@ -232,10 +233,18 @@ void Compressor::end_segment()
             uint32_t flags = pp_coded_ ? ZPQ_FLAG_PP : 0u;
             if (!modeled) flags |= ZPQ_FLAG_NOEOF;
             if (block_) {
-                std::vector<uint8_t> out(stage_.size() * 17 + 4096);
+                // Worst-case expansion is ~16x (p16 >= 3/65536); real data needs input + a little.  A block's first
+                // segment leaves the block untouched on ZPQ_E_OVERFLOW (zpq_block_encode_segment), so it starts with
+                // a tight buffer and retries once with the worst case; later segments get the worst case at once.
+                const size_t worst = stage_.size() * 17 + 4096, tight = stage_.size() + stage_.size() / 8 + 4096;
+                std::vector<uint8_t> out(segs_in_block_ == 0 ? tight : worst);
                 size_t n = 0;
                 err_ = zpq_block_encode_segment(block_, stage_.data(), stage_.size(), flags, out.data(), out.size(), &n);
-                if (err_ == ZPQ_OK) output_->write(out.data(), (int)n);
+                if (err_ == ZPQ_E_OVERFLOW && segs_in_block_ == 0) {
+                    out.resize(worst);
+                    err_ = zpq_block_encode_segment(block_, stage_.data(), stage_.size(), flags, out.data(), out.size(), &n);
+                }
+                if (err_ == ZPQ_OK) { output_->write(out.data(), (int)n); segs_in_block_++; }
             } else if (err_ == ZPQ_OK) err_ = ZPQ_E_NODEVICE;
         }
         const std::vector<uint8_t> h = sha1_.result();
@@ -409,19 +418,35 @@ bool Decompresser::decode_segment()
 {
     decoded_ = true;
     const size_t remain = in_.size() - pos_;
+    // The segment's end is only known once it is decoded.  Its coded bytes cannot contain the 16-byte block
+    // locator (a 2^-128 event), so the next locator bounds the input; should the decoder nevertheless run to
+    // the end of that window, the call is repeated on everything that follows (what Decoder's Reader would see).
+    static const uint8_t tag16[16] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3, 0x7a, 0x50, 0x51};
+    size_t window = remain;
+    if (remain > 16) {
+        const void *m = memmem(in_.data() + pos_, remain, tag16, sizeof tag16);
+        if (m) window = (size_t)(static_cast<const uint8_t *>(m) - (in_.data() + pos_));
+    }
     std::vector<uint8_t> out;
-    size_t cap = remain * 64 + 65536, n = 0, consumed = 0;
+    // first try: 8x the coded size (the batch entry points move at most 4 GiB per slab), grown on ZPQ_E_OVERFLOW
+    const size_t cap_max = 0xFFFFFF00ull;
+    size_t cap = std::min<size_t>(window * 8 + 65536, (size_t)256 << 20), n = 0, consumed = 0;
     uint32_t first = 0xFFFFFFFFu;
-    for (int attempt = 0; attempt < 8; attempt++) {
+    for (int attempt = 0; attempt < 12; attempt++) {
         out.resize(cap);
         zpq_block *blk = block_;
-        err_ = zpq_block_decode_segment(blk, in_.data() + pos_, remain, ZPQ_FLAG_PP, out.data(), cap, &n, &consumed,
+        err_ = zpq_block_decode_segment(blk, in_.data() + pos_, window, ZPQ_FLAG_PP, out.data(), cap, &n, &consumed,
                                         &final_code_, &first);
-        if (err_ != ZPQ_E_OVERFLOW) break;
-        // a retry must start from the same model state: overflow can only be retried on a
+        const bool ran_out = err_ == ZPQ_OK && window < remain && consumed >= window;
+        if (err_ != ZPQ_E_OVERFLOW && !ran_out) break;
+        // a retry must start from the same model state: that is only possible on a
         // fresh block, which is the case for the first segment; otherwise report it
-        if (segs_in_block_ != 0) break;
-        cap *= 8;
+        if (segs_in_block_ != 0) { if (ran_out) err_ = ZPQ_E_HEADER; break; }
+        if (ran_out) window = remain;
+        else {
+            if (cap >= cap_max) break;
+            cap = std::min<size_t>(cap * 8, cap_max);
+        }
         zpq_block_destroy(block_); block_ = nullptr;
         if (zpq_block_create(ctx_, model_, &block_) != ZPQ_OK) { err_ = ZPQ_E_NOMEM; break; }
     }
@@ -466,18 +491,18 @@ bool Decompresser::decompress_store(int n)              // decompressor.v:518-58
     while (count < limit) {
         if (store_count_ == 0) {
             const int b0 = get(), b1 = get(), b2 = get(), b3 = get();
-            if (b0 < 0 || b1 < 0 || b2 < 0 || b3 < 0) return false;
+            if (b0 < 0 || b1 < 0 || b2 < 0 || b3 < 0) { err_ = ZPQ_E_HEADER; return false; }   // stream ends inside the segment
             store_count_ = ((uint32_t)b0 << 24) | ((uint32_t)b1 << 16) | ((uint32_t)b2 << 8) | (uint32_t)b3;
             if (store_count_ == 0) return false;
             if (first_seg_) {
-                if (get() < 0) return false;
+                if (get() < 0) { err_ = ZPQ_E_HEADER; return false; }
                 store_count_--;
                 first_seg_ = false;
                 if (store_count_ == 0) continue;
             }
         }
         const int c = get();
-        if (c < 0) return false;
+        if (c < 0) { err_ = ZPQ_E_HEADER; return false; }   // truncated chunk: same bool as the reference, but not "OK"
         sha1_.put(c);
         if (output_) output_->put(c);
         store_count_--;
@@ -505,6 +530,9 @@ void Decompresser::read_segment_end()
         while (ok) { const int c = get(); if (c < 0) break; if (c != 0) { marker = c; break; } }
     } else {
         marker = get();
+        // a store segment must end in 253 (+ SHA-1) or 254; the reference reads on regardless ("robustness",
+        // decompressor.v:629-632) -- so does this, but the segment is not reported as OK
+        if (marker != 253 && marker != 254 && err_ == ZPQ_OK) err_ = ZPQ_E_HEADER;
     }
     has_stored_sha1_ = false;
     if (marker == 253) {                                 // stored SHA-1: read, compared, result unused (:608-628)

@@ -301,6 +301,12 @@ extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegi
     if (!out || len < 0 || (len > 0 && !hdr)) return ZPQ_E_ARG;
     *out = nullptr;
     if (len > ZPQ_MAX_HDR) return ZPQ_E_TOOBIG;
+    // Offsets index the header on the host (component walk, program-shape compare) and on the device (program
+    // fetch): anything outside the header is refused.  hend < hbegin = an empty program, as ZPAQL.run treats it
+    // (pc outside [hbegin, hend) stops at once, zpaql.v:170-174).
+    if (cend < 0 || hbegin < 0) return ZPQ_E_ARG;
+    if (cend > len || hbegin > len || hend > len) return ZPQ_E_HEADER;
+    if (hend < hbegin) hend = hbegin;
     int tst = ZPQ_OK;
     const Tables &T = tables(&tst);
     if (tst != ZPQ_OK) return tst;
