@@ -147,6 +147,7 @@ public:
     std::vector<uint8_t> get_sha1() { return sha1_.result(); }
     int last_error() const { return err_; }
     size_t position() const { return pos_; }                       // bytes of the input stream consumed so far
+    bool block_ended() const { return state_ == kStart; }          // find_filename met the end-of-block marker (:364-368)
     // digest stored behind marker 253 of the segment just ended (the reference reads and drops it, :608-628)
     bool stored_sha1(uint8_t out20[20]) const { if (has_stored_sha1_) for (int i = 0; i < 20; i++) out20[i] = stored_sha1_[i]; return has_stored_sha1_; }
 private:

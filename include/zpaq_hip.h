@@ -73,10 +73,12 @@ void zpq_ctx_destroy(zpq_ctx *);
 int zpq_ctx_sync(zpq_ctx *);
 void *zpq_ctx_stream(zpq_ctx *); /* the hipStream_t all launches of this ctx go to */
 int zpq_ctx_device(const zpq_ctx *); /* HIP device index the ctx was created on */
-/* Upper bound on state-slot memory this ctx may hold (default: 75% of free HBM). */
+/* Upper bound on state-slot memory this ctx may hold (default: 85% of the HBM free at zpq_ctx_create). */
 int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
-/* Largest block (bytes) the caller will submit to the chain kernel for models with huge hash
- * tables (levels 4-5): sizes their compact line store.  Default 65536.  A bigger block gets
+/* Largest block (bytes) the caller will submit to the chain kernel: sizes the compact line store
+ * that stands in for every hash table larger than it (a block of N bytes touches at most 2(N+2)
+ * lines per table, predictor.v:495-532,558-560; the store holds 1.25x that).  Default 65536: level 1's
+ * ISSE and all tables of levels 3-5 use the store, level 2's 4 MiB tables stay dense.  A bigger block gets
  * ZPQ_E_TOOBIG in status[] instead of wrong output. */
 int zpq_ctx_set_max_block_bytes(zpq_ctx *, uint64_t bytes);
 /* Resident blocks (state slots) the last batch call used; for reporting. */

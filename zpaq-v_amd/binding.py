@@ -50,6 +50,7 @@ def lib():
     L.zpq_ctx_stream.argtypes = [vp]
     L.zpq_ctx_stream.restype = vp
     L.zpq_ctx_set_state_budget.argtypes = [vp, u64]
+    L.zpq_ctx_set_max_block_bytes.argtypes = [vp, u64]
     L.zpq_ctx_last_slots.argtypes = [vp]
     L.zpq_ctx_resident_capacity.argtypes = [vp, vp, u32]
     L.zpq_ctx_last_kernel_ms.argtypes = [vp]

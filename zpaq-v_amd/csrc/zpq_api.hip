@@ -88,8 +88,9 @@ struct zpq_ctx {
     int16_t *d_squash = nullptr, *d_stretch = nullptr, *d_dt2k = nullptr;
     uint32_t *d_dt = nullptr, *d_stretch_c = nullptr;
     uint8_t *d_ns = nullptr;
-    std::map<uint64_t, DevModel> models;   // key = model id * 64 + compact-store log2 (0 = dense layout)
-    int sparse_log2 = 18;                  // line-store capacity for blocks up to 64 KiB (+ PP byte)
+    std::map<uint64_t, DevModel> models;   // key = model id << 32 | compact-store capacity (0 = dense layout)
+    uint32_t sparse_cap = 0;               // line-store capacity (lines) for the largest block the caller submits
+    uint32_t sparse_pct = 125;             // capacity = this percentage of the lines a largest block can touch
     DevBuf slots;
     uint64_t budget = 0;
     int last_slots = 0;
@@ -161,8 +162,14 @@ static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
     HIPCK(hipMemcpy(c->d_ns, T.ns, 1024, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->d_stretch_c, T.stretch_c, sizeof T.stretch_c, hipMemcpyHostToDevice));
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->budget = (uint64_t)fr / 4 * 3;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->budget = (uint64_t)fr / 100 * 85;
     else c->budget = 64ull << 30;
+    {
+        const char *ev = getenv("ZPQ_SPARSE_PCT");             // tuning knob: store capacity as % of the touched-line bound
+        const int pct = ev ? atoi(ev) : 0;
+        if (pct >= 101 && pct <= 400) c->sparse_pct = (uint32_t)pct;
+    }
+    zpq_ctx_set_max_block_bytes(c, 65536);
     return ZPQ_OK;
 }
 
@@ -201,11 +208,14 @@ extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes)
 extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
 {
     if (!c) return ZPQ_E_ARG;
-    // a block of N bytes (+ PP byte) probes each hash table 2(N+1) times; keep the store <= 60 % full
+    // A block of N bytes (+ PP byte) probes each hash table 2(N+1) times (predictor.v:558-560: once per nibble),
+    // so it touches at most that many 64-byte lines.  The store holds sparse_pct % of that bound: probing is
+    // linear over 4-slot groups, a worst-case block (every probe a new line) ends at 80 % load.
     const uint64_t probes = 2 * (bytes + 2);
-    int lg = 12;
-    while (lg < 26 && (uint64_t)(0.6 * (double)(1ull << lg)) < probes) lg++;
-    c->sparse_log2 = lg;
+    uint64_t cap = (probes * c->sparse_pct + 99) / 100 + 16;
+    cap = (cap + 3) & ~3ull;
+    if (cap > (1ull << 25)) cap = 1ull << 25;               // line offsets are 32-bit in the kernel
+    c->sparse_cap = (uint32_t)cap;
     return ZPQ_OK;
 }
 extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return c ? c->last_slots : 0; }
@@ -219,9 +229,9 @@ extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
     return ms;
 }
 
-static int get_dev_model(zpq_ctx *c, const zpq_model *m, const DModel &layout, int sparse_log2, DevModel *out)
+static int get_dev_model(zpq_ctx *c, const zpq_model *m, const DModel &layout, uint32_t sparse_cap, DevModel *out)
 {
-    const uint64_t key = m->id * 64 + (uint64_t)sparse_log2;
+    const uint64_t key = (m->id << 32) | (uint64_t)sparse_cap;
     auto it = c->models.find(key);
     if (it != c->models.end()) { *out = it->second; return ZPQ_OK; }
     DevModel dm;
@@ -250,43 +260,73 @@ struct BatchArgs {
 // What a batch call will launch: kernel family, slot layout, resident slots and grid.
 struct Plan {
     bool chain = false, lanes = false;
-    int sp = 0;                  // compact line store capacity (log2 lines), 0 = dense tables
+    uint32_t sp = 0;             // compact line store capacity (lines), 0 = dense tables
     const DModel *M = nullptr;   // layout the kernels see (dense or compact)
     int nslots = 0, grid = 0, bpw = 0;
 };
+
+// resident slots / grid of the chain kernel for one slot layout
+static int plan_chain(zpq_ctx *c, const DModel &M, int nblocks, int *nslots_out, int *grid_out, int *bpw_out)
+{
+    const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)nblocks;
+    if (max_by_mem == 0) return ZPQ_E_NOMEM;
+    int bpw = 0;
+    const uint64_t can_hold = max_by_mem < (uint64_t)nblocks ? max_by_mem : (uint64_t)nblocks;
+    if (!zpq_chain_plan(&M, (int)can_hold, c->cus, &bpw)) return ZPQ_E_INTERNAL;
+    int nwg = (nblocks + bpw - 1) / bpw;
+    const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
+    if (nwg > cap_wg) nwg = cap_wg;
+    int nslots = nwg * bpw;
+    if ((uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;      // last workgroup partly idle
+    if (nslots > nblocks) nslots = nblocks;
+    *nslots_out = nslots;
+    *grid_out = (nslots + bpw - 1) / bpw;
+    *bpw_out = bpw;
+    return ZPQ_OK;
+}
 
 static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P)
 {
     P->chain = m->d.fast_kind && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
                !trace && !own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
-    // chain kernel + huge hash tables (levels 4-5): compact line store layout of the slot
     static thread_local DModel sparse_layout;
     P->sp = 0;
-    if (P->chain) {
-        const char *ev = getenv("ZPQ_SPARSE_FORCE_LOG2");        // tests: exercise the store on small models
-        const int cap = ev ? atoi(ev) : c->sparse_log2;
-        if (cap >= 8 && cap <= 26 && zpq_sparse_layout(m->d, cap, &sparse_layout)) P->sp = cap;
-    }
-    P->M = P->sp ? &sparse_layout : &m->d;
-    const DModel &M = *P->M;
+    P->M = &m->d;
     // everything else with up to 64 components: one block per wave, lane i = component i
     P->lanes = !P->chain && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY | ZB_KEEP_STATE)) &&
                !trace && !own_slot && zpq_lanes_supported(&m->d);
-    const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)nblocks;
-    if (max_by_mem == 0 && !own_slot) return ZPQ_E_NOMEM;
     int nslots, grid, bpw = 0;
     if (P->chain) {
-        const uint64_t can_hold = max_by_mem < (uint64_t)nblocks ? max_by_mem : (uint64_t)nblocks;
-        if (!zpq_chain_plan(&M, (int)can_hold, c->cus, &bpw)) return ZPQ_E_INTERNAL;
-        int nwg = (nblocks + bpw - 1) / bpw;
-        const int cap_wg = zpq_chain_max_wgs(&M, c->cus);
-        if (nwg > cap_wg) nwg = cap_wg;
-        nslots = nwg * bpw;
-        if ((uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;      // last workgroup partly idle
-        if (nslots > nblocks) nslots = nblocks;
-        nwg = (nslots + bpw - 1) / bpw;
-        grid = nwg;
+        // Dense tables or the compact line store?  The store costs ~120 instructions per nibble and hashed
+        // component, so it is used where it pays: when it lets the batch finish in fewer rounds of resident
+        // blocks (levels 3-5 at scale, level 1 beyond ~6900 blocks), or when a dense slot is so large
+        // (levels 4-5: 385 MiB / 2 GiB) that clearing it per block costs more than the store does.
+        int dn = 0, dg = 0, db = 0;
+        const int rcd = plan_chain(c, m->d, nblocks, &dn, &dg, &db);
+        const char *ev = getenv("ZPQ_SPARSE_FORCE_LOG2");        // tests: exercise the store on small models
+        const int lg = ev ? atoi(ev) : 0;
+        const bool forced = lg >= 8 && lg <= 25;
+        const uint32_t cap = forced ? (1u << lg) : c->sparse_cap;
+        const char *mode = getenv("ZPQ_SPARSE_MODE");            // tuning knob: "never" / "always"
+        const bool never = mode && !strcmp(mode, "never"), always = forced || (mode && !strcmp(mode, "always"));
+        int sn = 0, sg = 0, sb = 0;
+        bool use_sparse = false;
+        if (!never && zpq_sparse_layout(m->d, cap, &sparse_layout) && plan_chain(c, sparse_layout, nblocks, &sn, &sg, &sb) == ZPQ_OK) {
+            if (rcd != ZPQ_OK || always || m->d.slot_bytes > (256ull << 20)) use_sparse = true;
+            else {
+                const int rounds_d = (nblocks + dn - 1) / dn, rounds_s = (nblocks + sn - 1) / sn;
+                use_sparse = rounds_s < rounds_d;
+            }
+        }
+        if (use_sparse) { P->sp = cap; P->M = &sparse_layout; nslots = sn; grid = sg; bpw = sb; }
+        else {
+            if (rcd != ZPQ_OK) return rcd;
+            nslots = dn; grid = dg; bpw = db;
+        }
     } else {
+        const DModel &M = *P->M;
+        const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)nblocks;
+        if (max_by_mem == 0 && !own_slot) return ZPQ_E_NOMEM;
         nslots = nblocks;
         const int cap_res = c->cus * (P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
         if (nslots > cap_res) nslots = cap_res;

@@ -345,9 +345,12 @@ bool next_block(const uint8_t *a, size_t n, size_t &pos, BlockRec &b, bool at_re
     return true;
 }
 
-// every segment of one block through the sequential front end; returns how far into [from, to) the reader got
-size_t replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool want_data, std::vector<ArchiveFile> *out)
+// every segment of one block through the sequential front end; returns how far into [from, to) the reader got.
+// *clean = the block decoded without a complaint and ended in its end-of-block marker, i.e. the returned position
+// is where an undamaged stream continues (a damaged block's reader position means nothing).
+size_t replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool want_data, std::vector<ArchiveFile> *out, bool *clean)
 {
+    *clean = false;
     FileReader r(std::vector<uint8_t>(a + from, a + to));
     Decompresser d(ctx);
     d.set_input(&r);
@@ -355,6 +358,7 @@ size_t replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool
         if (d.last_error() != ZPQ_OK) { ArchiveFile f; f.status = d.last_error(); out->push_back(std::move(f)); }
         return from + d.position();
     }
+    bool ok = true;
     while (d.find_filename()) {
         ArchiveFile f;
         f.name = d.get_filename();
@@ -370,9 +374,11 @@ size_t replay_block(zpq_ctx *ctx, const uint8_t *a, size_t from, size_t to, bool
         f.size = fw.bytes().size();
         if (want_data) f.data = fw.bytes();
         const int fst = f.status;
+        ok = ok && fst == ZPQ_OK && f.sha1_ok;
         out->push_back(std::move(f));
         if (fst != ZPQ_OK) break;
     }
+    *clean = ok && d.block_ended();
     return from + d.position();
 }
 
@@ -462,21 +468,31 @@ static int extract_segments(const std::vector<zpq_ctx *> &ctxs, const uint8_t *a
     }
     // ---- everything else, in archive order, following the sequential reader: `seq` is where it stands.
     //      A record that begins before `seq` lies inside the block just consumed (the reference never sees it);
-    //      a bare "zPQ" exactly at `seq` starts a block the locator search could not see.
+    //      a bare "zPQ" exactly at `seq` starts a block the locator search could not see.  Behind a DAMAGED block
+    //      the reader's position means nothing: the walk then resumes at the next locator (more forgiving than
+    //      the reference, whose reader would plough on through whatever follows).
     static const uint8_t zpq3[3] = {0x7a, 0x50, 0x51};
     size_t seq = 0;
     for (size_t i = 0; i <= blocks.size(); i++) {
         const size_t tag = i < blocks.size() ? blocks[i].tag_pos : n;
         if (tag < seq) continue;
         while (seq + 3 <= tag && memcmp(arc + seq, zpq3, 3) == 0 && !(i < blocks.size() && tag == seq)) {
-            const size_t stop = replay_block(ctx, arc, seq, tag, want_data, files);
-            if (stop <= seq) break;
+            bool clean = false;
+            const size_t stop = replay_block(ctx, arc, seq, tag, want_data, files, &clean);
+            if (!clean || stop <= seq) { seq = tag; break; }
             seq = stop;
         }
         if (i == blocks.size()) break;
         if (tag < seq) continue;                               // swallowed by a bare block just replayed
-        if (dec[i].done) { files->push_back(std::move(dec[i].f)); seq = dec[i].end; continue; }
-        seq = replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files);
+        if (dec[i].done) {
+            const bool clean = dec[i].f.sha1_ok && dec[i].f.status == ZPQ_OK;
+            files->push_back(std::move(dec[i].f));
+            seq = clean ? dec[i].end : tag + 1;
+            continue;
+        }
+        bool clean = false;
+        const size_t stop = replay_block(ctx, arc, blocks[i].tag_pos, blocks[i].next_tag, want_data, files, &clean);
+        seq = clean ? stop : tag + 1;
     }
     return ZPQ_OK;
 }

@@ -81,6 +81,7 @@ struct Cfg {
     int32_t vm_kind;
     int32_t g;                 // lanes per block chosen on the host (8 or 16)
     int32_t nch_spec;          // compile-time specialisation picked on the host: chain length (0 = runtime path)
+    int32_t sparse;            // some component uses a compact line store
     uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
     int32_t lds_mixw;          // byte offset inside the block's LDS state of u16[16]: the nibble's candidate MIX2 weights (decode)
@@ -141,7 +142,10 @@ struct BitCtx {
 // 1-3: 2/3/5 without, level 4: 6 with, level 5: 8 with): straight-line chain and broadcast.
 // NCH == 0: any chain model, runtime loops.
 // GG = lanes per ZPAQ block (16, or 8 when the model has <= 8 components).
-template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG>
+// SP = some hash table of the model lives in a compact line store (levels 1 and 3-5; level 2's tables are smaller
+// than a store and stay dense).  Only SP kernels carry the store's code: its collision walk -- a divergent loop
+// with global loads inside take_prefetched -- cost the dense level-2 encode 17 % by its mere presence.
+template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG, bool SP>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     constexpr int G = GG;            // shadows zpqc::G inside the kernel
@@ -194,17 +198,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // lanes without a hash table (idle, MIX2) run the same row loads against the first 64
     // bytes of the slot: no exec-masked branch around the loads (a branch join would make
     // the compiler wait for them at once and defeat the prefetch); only the store is masked
-    u8 *ht = hashed ? slot + C.ht_off : slot;
     const u32 ht_mask = hashed ? ((C.ht_len - 16u) & cfg.dbg_ht_and) : 0u;
-    // compact line store (levels 4-5): tags[cap] + 64-byte lines[cap] instead of the dense table
-    // Only the kernels that can meet a compact store carry its code (the MIX2 levels 4-5 and the runtime-loop
-    // kernel); in the dense-table kernels of levels 1-3 the mere presence of its collision walk -- a divergent
-    // branch with global loads inside take_prefetched -- cost 17 % of encode (measured: 251 -> 293 ms).
-    constexpr bool SPARSE = (NCH == 0) || MIXT;
-    const u32 sp_log2 = (SPARSE && hashed) ? C.sp_cap_log2 : 0u;
+    // compact line store: u32 tags[cap] (dense line index + 1, 0 = free) + 64-byte lines[cap] instead of the dense
+    // table.  cap is a multiple of 4, about 1.25x the lines the largest block can touch (zpq_ctx_set_max_block_bytes).
+    constexpr bool SPARSE = SP;
+    const u32 sp_cap = (SPARSE && hashed) ? C.sp_cap : 0u;
+    const u32 sp_groups = sp_cap >> 2;
     u32 *sp_tags = reinterpret_cast<u32 *>(slot + C.sp_tag_off);
-    u8 *sp_lines = slot + C.sp_line_off;
-    const u32 sp_mask = sp_log2 ? ((1u << sp_log2) - 1u) : 0u;
+    // every row access of this lane is tbase + a 32-bit byte offset: the dense table, or the store's line array
+    // (offsets, not pointers, so that the h0 ^ 16 / ^ 32 neighbours stay provably global addresses)
+    u8 *const tbase = hashed ? (sp_cap ? slot + C.sp_line_off : slot + C.ht_off) : slot;
     const int sizebits = C.a + 2;
     // Packed per-block state.  ISSE weights are 20-bit two's complement (clamp512k,
     // predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.  An ICM entry is
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         }
         const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
         u32 ch = 0;
-        u8 *raddr = ht;
+        u32 roff = 0;                                      // tbase offset of the row in X.r0..r3
 
         auto stretch_lds = stretch_of;
         // the stretch an ICM entry carries (meaningless on other lanes, where it is masked out)
@@ -321,16 +324,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
         // find_ht (predictor.v:495-532): the three candidate rows h0, h0^16, h0^32 share one
         // 64-byte line.  select_row resolves hit / victim with selects only.
-        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, u8 *pa, const u32 chk) {
-            u8 *pb = reinterpret_cast<u8 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);   // rows share a 64-B aligned line
-            u8 *pc = reinterpret_cast<u8 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
+        auto select_row = [&](const u32x4 A, const u32x4 Bq, const u32x4 Cq, const u32 pa, const u32 chk) {
+            const u32 pb = pa ^ 16u, pc = pa ^ 32u;                             // rows share a 64-B aligned line
             const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
             const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
             const bool va = qa <= qb && qa <= qc, vb = qb < qc;            // victim order (predictor.v:513-531)
             const bool hit = ma || mb || mc;
             const bool ua = ma || (!hit && va);
             const bool ub = !ua && (mb || (!hit && vb));
-            raddr = ua ? pa : (ub ? pb : pc);
+            roff = ua ? pa : (ub ? pb : pc);
             const u32x4 Rr = ua ? A : (ub ? Bq : Cq);
             X.r0 = hit ? Rr.x : chk; X.r1 = hit ? Rr.y : 0u; X.r2 = hit ? Rr.z : 0u; X.r3 = hit ? Rr.w : 0u;
         };
@@ -341,71 +343,107 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // update work.  If a requested row is the one being updated right now, the registers
         // win (exact forwarding in take_prefetched).
         u32x4 nA = {0, 0, 0, 0}, nB = {0, 0, 0, 0}, nC = {0, 0, 0, 0};
-        u8 *n_pa = ht;
-        u32 n_chk = 0, sp_claims = 0;
-        u32 n_key = 0, n_si = 0, n_tag = 0, n_off = 0;     // compact store: the probe in flight
-        auto sp_claim = [&](const u32 si, const u32 key) {   // a free slot becomes this line's (its 64 bytes are still zero)
-            if (sp_claims * 10u >= (sp_mask + 1u) * 9u) { status = ZPQ_E_TOOBIG; return; }   // store (nearly) full
-            sp_tags[si] = key;
-            sp_claims++;
+        u32 n_po = 0;                                      // tbase offset of candidate row A of the probe in flight
+        u32 n_chk = 0;
+        u32 n_key = 0, n_si = 0, n_off = 0;                // compact store: the probe in flight
+        u32x4 n_tags = {0, 0, 0, 0};
+        bool sp_full = false;
+        u32 sp_claims = 0;
+        const u32 sp_limit = sp_cap - (sp_cap >> 4);       // a block that needs more than 15/16 of the store is refused
+        auto load_rows = [&](const u32 po) {
+            nA = *reinterpret_cast<const u32x4 *>(tbase + po);
+            nB = *reinterpret_cast<const u32x4 *>(tbase + (po ^ 16u));
+            nC = *reinterpret_cast<const u32x4 *>(tbase + (po ^ 32u));
         };
         auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
             const u32 cx = hc + 16u * c8v;
             n_chk = (cx >> sizebits) & 255u;
             const u32 h0 = (cx * 16u) & ht_mask;
-            u8 *pa = ht + h0;
-            if (sp_log2) {
-                // dense line index -> slot of the compact store (open addressing, linear probing from a
-                // multiplicative hash).  The FIRST slot's rows are fetched together with its tag: when the tag
-                // turns out to be this line's, or free (claimed in take_prefetched; a free slot's line is still
-                // all-zero like an untouched dense line), that was the only memory round trip.  Only a real
-                // collision walks on, serially, in take_prefetched.
+            u32 po = h0;
+            if (SPARSE && sp_cap) {
+                // Dense line index -> slot of the compact store.  Open addressing over GROUPS of four slots: the home
+                // slot is mulhi(hash, cap) (capacity need not be a power of two); probing visits the home group's
+                // slots cyclically from the home slot, then the following groups the same way.  One 16-byte load
+                // brings the home group's four tags, and the HOME slot's rows are fetched with them: a line that
+                // sits in its home slot, or a new line (it takes the first free slot it meets, and a new line is all
+                // zero -- nothing to load), costs one memory round trip; only a line that was displaced when it
+                // was claimed needs a second one for its rows, and only a full group is walked past.
                 n_key = (h0 >> 6) + 1u;
-                n_si = ((h0 >> 6) * 0x9E3779B1u) >> (32u - sp_log2);
+                n_si = __umulhi(n_key * 0x9E3779B1u, sp_cap);
                 n_off = h0 & 48u;
-                n_tag = sp_tags[n_si];
-                pa = sp_lines + ((u64)n_si << 6) + n_off;
+                n_tags = *reinterpret_cast<const u32x4 *>(sp_tags + (n_si & ~3u));
+                po = (n_si << 6) + n_off;
             }
-            n_pa = pa;
-            nA = *reinterpret_cast<const u32x4 *>(pa);
-            nB = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);
-            nC = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
+            n_po = po;
+            load_rows(po);
         };
         // Consume the rows requested one nibble ago, THEN write the finished row back (so that
         // the wait for the loads does not also wait for a just-issued store), then the caller
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
         // is one of the candidates.
         auto take_prefetched = [&](const bool have_prev) {
-            if (sp_log2 && n_tag != n_key) {                  // compact store: the first slot was not (yet) this line's
-                u32 si = n_si;
-                if (n_tag == 0u) sp_claim(si, n_key);
-                else {
-                    for (u32 tries = 0; tries < sp_mask; tries++) {
-                        si = (si + 1u) & sp_mask;
-                        const u32 t = sp_tags[si];
-                        if (t == n_key) break;
-                        if (t == 0u) { sp_claim(si, n_key); break; }
+            bool claim = false;
+            u32 claim_si = 0;
+            if (SPARSE && sp_cap) {
+                const u32 o = n_si & 3u;
+                // slots of a group that end the probe -- the line's own tag, or a free slot -- as a 4-bit mask rotated
+                // so that bit j stands for slot (o + j) & 3: the lowest set bit is the first such slot met
+                auto probe_group = [&](const u32x4 T) -> u32 {
+                    const u32 mm = (min(T.x ^ n_key, T.x) == 0u ? 1u : 0u) | (min(T.y ^ n_key, T.y) == 0u ? 2u : 0u) |
+                                   (min(T.z ^ n_key, T.z) == 0u ? 4u : 0u) | (min(T.w ^ n_key, T.w) == 0u ? 8u : 0u);
+                    return ((mm * 17u) >> o) & 15u;
+                };
+                u32x4 T = n_tags;
+                u32 g = n_si >> 2;
+                u32 r = probe_group(T);
+                if (r == 0u && !sp_full) {                                     // home group full of other lines: walk on
+                    for (u32 tries = 1; tries < sp_groups; tries++) {
+                        g = (g + 1u == sp_groups) ? 0u : g + 1u;
+                        T = *reinterpret_cast<const u32x4 *>(sp_tags + 4u * g);
+                        r = probe_group(T);
+                        if (r) break;
                     }
-                    u8 *pa = sp_lines + ((u64)si << 6) + n_off;
-                    n_pa = pa;
-                    nA = *reinterpret_cast<const u32x4 *>(pa);
-                    nB = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 16u);
-                    nC = *reinterpret_cast<const u32x4 *>(reinterpret_cast<uintptr_t>(pa) ^ 32u);
+                }
+                const u32 idx = (o + (u32)__builtin_ctz(r | 16u)) & 3u;
+                const u32 t = (idx & 2u) ? ((idx & 1u) ? T.w : T.z) : ((idx & 1u) ? T.y : T.x);
+                const u32 si = 4u * g + idx;
+                if (r == 0u) { status = ZPQ_E_TOOBIG; sp_full = true; }        // every slot taken: the block is larger than promised
+                else if (t == 0u && ++sp_claims > sp_limit) { status = ZPQ_E_TOOBIG; sp_full = true; }   // (nearly) full: stop before probes get long
+                else if (t == 0u) {
+                    // claim: the line becomes this context's and starts out all zero, like an untouched dense line.
+                    // Its tag and its zeros are STORED further down, behind the consumption of the loads: a store
+                    // issued here would sit in front of the reload below in the in-order vmcnt queue.
+                    const u32x4 z4 = {0, 0, 0, 0};
+                    claim = true;
+                    claim_si = si;
+                    nA = z4; nB = z4; nC = z4;
+                    n_po = (si << 6) + n_off;
+                } else if (si != n_si) {                                       // displaced line: its rows were not the ones fetched
+                    n_po = (si << 6) + n_off;
+                    load_rows(n_po);
                 }
             }
             const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
-            u8 *const paddr = raddr;
-            const uintptr_t na = reinterpret_cast<uintptr_t>(n_pa), pp = reinterpret_cast<uintptr_t>(paddr);
-            const bool fa = have_prev && na == pp;
-            const bool fb = have_prev && (na ^ 16u) == pp;
-            const bool fc = have_prev && (na ^ 32u) == pp;
+            const u32 poff = roff;
+            const bool fa = have_prev && n_po == poff;
+            const bool fb = have_prev && (n_po ^ 16u) == poff;
+            const bool fc = have_prev && (n_po ^ 32u) == poff;
             const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
-            select_row(A, Bq, Cq, n_pa, n_chk);
-            // keep the store BELOW the wait for the loads above (vmcnt is in-order: a store issued
+            select_row(A, Bq, Cq, n_po, n_chk);
+            // keep the stores BELOW the wait for the loads above (vmcnt is in-order: a store issued
             // first would be waited for as well)
-            u8 *paddr2 = paddr;
-            asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(paddr2) : "v"(X.r0), "v"(X.r3));
-            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(paddr2) = Rp;
+            u32 poff2 = poff, cpo = n_po & ~63u;
+            asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(poff2), "+v"(cpo) : "v"(X.r0), "v"(X.r3));
+            if (SPARSE && claim) {
+                const u32x4 z4 = {0, 0, 0, 0};
+                u8 *line = tbase + cpo;
+                sp_tags[claim_si] = n_key;
+                *reinterpret_cast<u32x4 *>(line) = z4;
+                *reinterpret_cast<u32x4 *>(line + 16) = z4;
+                *reinterpret_cast<u32x4 *>(line + 32) = z4;
+                *reinterpret_cast<u32x4 *>(line + 48) = z4;
+            }
+            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;
         };
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
         auto run_vm = [&](const u32 byte) -> u32 {
@@ -856,8 +894,8 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         const int nch = cfg->nisse_end;
         bool spec = cfg->has_mix2 ? (nch == 6 || nch == 8) : (nch == 2 || nch == 3 || nch == 5);
         bool any_sparse = false;
-        for (int c = 0; c < M->n; c++) any_sparse = any_sparse || M->comp[c].sp_cap_log2 != 0;
-        if (any_sparse && !cfg->has_mix2) spec = false;       // the plain-chain kernels are dense-only: use the runtime-loop kernel
+        for (int c = 0; c < M->n; c++) any_sparse = any_sparse || M->comp[c].sp_cap != 0;
+        cfg->sparse = any_sparse ? 1 : 0;
         cfg->nch_spec = spec ? nch : 0;
         if (spec) cfg->g = (M->n <= 8) ? 8 : 16;              // specialised kernels exist for one G each
     }
@@ -940,27 +978,30 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
     const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
     // encode uses the pipelined bit step, decode the plain one (measured, see above)
-#define ZPQ_LAUNCH(D, N, MX, GGv)                                                                        \
+#define ZPQ_LAUNCH(D, N, MX, GGv, SPv)                                                                   \
     do {                                                                                                 \
         constexpr bool S_ = (D) ? (ZPQ_CHAIN_SPEC_DEC != 0) : (ZPQ_CHAIN_SPEC_ENC != 0);                 \
-        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S_, N, MX, GGv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((zpqc::k_chain<D, S_, N, MX, GGv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S_, N, MX, GGv, SPv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqc::k_chain<D, S_, N, MX, GGv, SPv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
     } while (0)
+#define ZPQ_LAUNCH_SP(D, N, GGv)                                                                         \
+    do { if (cfg.sparse) ZPQ_LAUNCH(D, N, false, GGv, true); else ZPQ_LAUNCH(D, N, false, GGv, false); } while (0)
 #define ZPQ_DISPATCH(D)                                                                                  \
     do {                                                                                                 \
         switch (cfg.nch_spec) {                                                                          \
-        case 2: ZPQ_LAUNCH(D, 2, false, 8); break;      /* level 1 */                                    \
-        case 3: ZPQ_LAUNCH(D, 3, false, 8); break;      /* level 2 */                                    \
-        case 5: ZPQ_LAUNCH(D, 5, false, 8); break;      /* level 3 */                                    \
-        case 6: ZPQ_LAUNCH(D, 6, true, 8); break;       /* level 4 */                                    \
-        case 8: ZPQ_LAUNCH(D, 8, true, 16); break;      /* level 5 */                                    \
+        case 2: ZPQ_LAUNCH_SP(D, 2, 8); break;          /* level 1 */                                    \
+        case 3: ZPQ_LAUNCH_SP(D, 3, 8); break;          /* level 2 */                                    \
+        case 5: ZPQ_LAUNCH_SP(D, 5, 8); break;          /* level 3 */                                    \
+        case 6: ZPQ_LAUNCH(D, 6, true, 8, true); break;       /* level 4 */                              \
+        case 8: ZPQ_LAUNCH(D, 8, true, 16, true); break;      /* level 5 */                              \
         default:                                                                                         \
-            if (cfg.g == 8) ZPQ_LAUNCH(D, 0, false, 8); else ZPQ_LAUNCH(D, 0, false, 16);                \
+            if (cfg.g == 8) ZPQ_LAUNCH(D, 0, false, 8, true); else ZPQ_LAUNCH(D, 0, false, 16, true);    \
             break;                                                                                       \
         }                                                                                                \
     } while (0)
     if (decode) ZPQ_DISPATCH(true); else ZPQ_DISPATCH(false);
 #undef ZPQ_DISPATCH
+#undef ZPQ_LAUNCH_SP
 #undef ZPQ_LAUNCH
     return ZPQ_OK;
 }

@@ -23,9 +23,10 @@ struct DComp {
     uint32_t cm_len, ht_len, a16_len;
     uint32_t cm_fill, cm_fill_val, cm_pat_len;  // ZF_*, constant or image offset (u32 words), pattern words
     uint32_t a16_fill;           // initial u16 value of every a16 entry
-    uint32_t sp_cap_log2;        // 0 = dense hash table; else log2 of the compact line store's capacity (lines)
+    uint32_t sp_cap;             // 0 = dense hash table; else capacity (lines, a multiple of 4) of the compact line store
     uint64_t cm_off, ht_off, a16_off;  // byte offsets inside the state slot
-    uint64_t sp_tag_off, sp_line_off;  // compact line store: u32 tags[cap] (line index + 1, 0 = free), 64-B lines[cap]
+    uint64_t sp_tag_off, sp_line_off;  // compact line store: u32 tags[cap] (dense line index + 1, 0 = free) inside the zeroed
+                                       // part of the slot, 64-B lines[cap] behind it (a line is zeroed when it is claimed)
 };
 
 // Mutable per-component scalars that outlive a segment (MATCH: a=len b=offset

@@ -22,9 +22,10 @@ uint64_t tables_fnv(int which);
 
 }  // namespace zpq
 
-// Re-lay a model's state slot with a compact line store (capacity 2^cap_log2 lines) for every
-// ICM/ISSE hash table that is at least 2x larger than the store; false if none qualifies.
-bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out);
+// Re-lay a model's state slot with a compact line store (capacity `cap` lines, a multiple of 4) for every
+// ICM/ISSE hash table that is larger than the store; false if none qualifies.  The zeroed prefix of the slot
+// (zero_bytes) then ends before the stores' line arrays: a line is cleared when it is claimed.
+bool zpq_sparse_layout(const DModel &dense, uint32_t cap, DModel *out);
 
 // The HCOMP shape every shipped level >= 2 uses (levels.v:126-141 and on):
 //   b=c c-- *c=a d=0 (hash *d=a d++) x K  hash *d=a halt

@@ -433,24 +433,26 @@ extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegi
 // level 5) is replaced by `cap` line slots plus a tag per slot (line index + 1).  Untouched
 // lines are zero in the dense table and lines are zeroed before use here, so the two are
 // indistinguishable to the coder ("hard parts").
-bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out)
+bool zpq_sparse_layout(const DModel &dense, uint32_t cap, DModel *out)
 {
     *out = dense;
     DModel &D = *out;
-    const uint64_t store = (64ull + 4ull) << cap_log2;
+    if (cap < 16 || (cap & 3u)) return false;
+    const uint64_t store = (64ull + 4ull) * cap;
     bool any = false;
     uint64_t off = D.m_off;
     off = align_up(off + D.mlen, 256);
     auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes, 256); return o; };
+    // everything that has to start out zero (or is initialised in-kernel) first ...
     for (int i = 0; i < D.n; i++) {
         DComp &c = D.comp[i];
+        c.sp_cap = 0;
         if (c.cm_len) c.cm_off = take(4ull * c.cm_len);
         if (c.ht_len) {
             const bool hashed = c.type == ZT_ICM || c.type == ZT_ISSE;
-            if (hashed && (uint64_t)c.ht_len >= 2 * store) {
-                c.sp_cap_log2 = (uint32_t)cap_log2;
-                c.sp_tag_off = take(4ull << cap_log2);
-                c.sp_line_off = take(64ull << cap_log2);
+            if (hashed && (uint64_t)c.ht_len > store) {
+                c.sp_cap = cap;
+                c.sp_tag_off = take(4ull * cap);
                 c.ht_off = 0;
                 any = true;
             } else {
@@ -459,8 +461,13 @@ bool zpq_sparse_layout(const DModel &dense, int cap_log2, DModel *out)
         }
         if (c.a16_len) c.a16_off = take(2ull * c.a16_len);
     }
+    D.zero_bytes = align_up(off, 256);
+    // ... then the line arrays, which need no clearing: claiming a free slot clears its line
+    for (int i = 0; i < D.n; i++) {
+        DComp &c = D.comp[i];
+        if (c.sp_cap) c.sp_line_off = take(64ull * cap);
+    }
     D.slot_bytes = align_up(off, 256);
-    D.zero_bytes = D.slot_bytes;
     return any;
 }
 
