@@ -23,7 +23,8 @@ class ZpqError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libzpaq_hip.so")
+    # ZPQ_LIB_PATH: another build of the same library (kernel experiments, tools/variants.sh)
+    return os.environ.get("ZPQ_LIB_PATH") or os.path.join(HERE, "lib", "libzpaq_hip.so")
 
 
 def lib():

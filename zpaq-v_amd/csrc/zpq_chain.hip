@@ -281,6 +281,24 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         const u32 ndw = (nin + mis + 3u) >> 2;              // dwords that hold at least one valid byte
         u32 win0 = ndw > 0 ? src4[0] : 0u, win1 = ndw > 1 ? src4[1] : 0u;
         u32 wdw = 0;                                       // dword index held in win0
+        // Encode walks the input one byte per iteration, so its window needs no decision: every iteration slides by
+        // register moves and re-requests the dword behind the window UNCONDITIONALLY; the value is first looked at an
+        // iteration later.  (A load inside the "crossed a dword" branch was waited for right at the branch join --
+        // an exposed memory round trip whenever ANY lane of the wave crossed, i.e. almost every byte once lanes of
+        // a block work on different bytes.)  Past the end the clamped address re-reads the last dword; the byte is
+        // masked by pos < nin.
+        const u32 *const enc4 = ndw ? src4 : reinterpret_cast<const u32 *>(B.in_off);   // nin == 0: any readable dword
+        const u32 enc_last = ndw ? ndw - 1u : 0u;
+        if (!DEC) win1 = enc4[min(1u, enc_last)];
+        auto enc_byte = [&](u32 pos) -> u32 {              // src[pos], pos advancing by at most one dword per call
+            const u32 vp = pos + mis;
+            const bool slide = (vp >> 2) != wdw;
+            win0 = slide ? win1 : win0;
+            wdw = slide ? wdw + 1u : wdw;
+            win1 = enc4[min(wdw + 1u, enc_last)];
+            const u32 c = (win0 >> ((vp & 3u) * 8u)) & 255u;
+            return pos < nin ? c : 0u;
+        };
         auto in_byte = [&](u32 pos) -> u32 {               // src[pos] for pos in the current/next dword; 0 past the end
             const u32 vp = pos + mis;
             if ((vp >> 2) != wdw) {                        // crossed into win1: slide and prefetch one more dword
@@ -564,9 +582,19 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
         };
 
+#ifdef ZPQ_NO_SKEW
+        constexpr bool SKEW = false;
+#else
+        constexpr bool SKEW = !DEC && NCH > 0;              // byte-skewed chain pipeline (see the main loop)
+#endif
+        i32 pout[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // this lane's predictions for the byte it is coding
+        i32 pin_cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // its predecessor's predictions for that byte
+        i32 pj_cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // MIX2 lane: the predecessor's input (= p[j])
+
         auto bitstep = [&](auto kc, auto nbc) {
             constexpr int K = decltype(kc)::value;
             constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;   // bit of the byte this step codes (7..0)
+            constexpr int KB = 7 - bit;                               // its position in coding order (0..7)
             // (plain form: cur_* of bits 1..3 were fetched at the end of the previous bit step, see (4b))
             const u32 s = cur_s;
             const i32 yk = DEC ? 0 : (i32)((ch >> bit) & 1u);  // encode knows its bit up front
@@ -598,7 +626,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 pin = me ? pv : pin;
                 p = me ? pn : p;
             };
-            if (NCH) {
+            if constexpr (SKEW) {
+                // every ISSE lane at once, each on its own byte, fed by what its predecessor handed over
+                pin = pin_cur[KB];
+                const i32 pn = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);
+                p = is_icm ? cur_pst : pn;
+            } else if (NCH) {
 #pragma unroll
                 for (int i = 1; i < (NCH ? NCH : 1); i++) chain_step(i);
             } else {
@@ -607,8 +640,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             i32 pj = 0, pk = 0, wmix = 0;
             u32 mcx = 0;
             if (has_mix2) {
-                pj = row_bcast(p, row_base + mix_j);
-                pk = row_bcast(p, row_base + mix_k);
+                if constexpr (SKEW) { pj = pj_cur[KB]; pk = pin_cur[KB]; }
+                else {
+                    pj = row_bcast(p, row_base + mix_j);
+                    pk = row_bcast(p, row_base + mix_k);
+                }
                 if (!DEC && mixreg) {
                     // encode: the byte's eight weights sit in registers since the byte began (mix_byte_begin)
                     wmix = (i32)mw[7 - bit];
@@ -622,6 +658,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
                 }
             }
+            if constexpr (SKEW) pout[KB] = p;
             const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li]) (predictor.v:193-202,667)
             // ---- (3) off the critical path: the ICM's stretch for the next bit, for both
             //          outcomes, with this bit's cm update forwarded when the state repeats
@@ -742,10 +779,24 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
         prefetch_rows(0u, 1u);                             // first nibble of the first byte: h = 0, c8 = 1
         if (DEC && mixreg) mixw_request(0u, 1u);
-        for (u32 bi = 0; bi < total; bi++) {
+        // Encode, specialised kernels: the prediction chain as a PIPELINE over bytes.  Every context, bit and
+        // bit-history state of the encoder is a function of the input alone; only predictions flow down the chain.
+        // So in iteration `it` lane c works on byte it - c: the ICM is one byte ahead of the first ISSE, which is one
+        // byte ahead of the next, ...; a lane's eight predictions of a byte are handed to its successor by eight DPP
+        // moves when the iteration ends.  Inside an iteration no lane waits for another: the per-bit dependent chain
+        // ICM -> ISSE -> ... -> coder (one DPP + multiply + clamp per link, in series) becomes one link per bit.
+        // The coder stays on the last component's lane and so sees bytes in order; it - c < 0 or >= total: lane idle.
+        const u32 skew_delay = SKEW ? (u32)li : 0u;
+        const u32 iters = SKEW ? total + (u32)last : total;
+        for (u32 it = 0; it < iters; it++) {
+            const u32 bi = it - skew_delay;
+            // (lanes beyond the last component stay in step on dummy tables: masking them off made level 1 30 % slower --
+            //  measured 286 vs 219 ms, cause not understood)
+            if (!SKEW || bi < total) {
             if (!DEC) {
-                if (B.flags & ZPQ_FLAG_PP) ch = (bi == 0) ? 0u : in_byte(bi - 1);
-                else ch = in_byte(bi);
+                const u32 cpos = (B.flags & ZPQ_FLAG_PP) ? bi - 1u : bi;
+                const u32 cb = enc_byte((B.flags & ZPQ_FLAG_PP) && bi == 0 ? 0u : cpos);
+                ch = ((B.flags & ZPQ_FLAG_PP) && bi == 0) ? 0u : cb;
             }
             // ---- EOF flag: encode(0,0) / decode(0)  (encoder.v:108, decoder.v:128)
             if (!DEC) {
@@ -802,6 +853,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     if (is_last && X.opos < cap) dst[X.opos] = (u8)byte;
                     X.opos++;                                 // uniform across the group when decoding
                     if (X.opos > cap) break;
+                }
+            }
+            }   // active
+            if constexpr (SKEW) {
+                // hand this byte's predictions down the chain (lane c-1 -> lane c); a MIX2 lane also receives its
+                // predecessor's INPUT, which is the other prediction it mixes (j = k - 1, checked on the host)
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (MIXT) pj_cur[k] = row_shr1(pin_cur[k]);
+                    pin_cur[k] = row_shr1(pout[k]);
                 }
             }
         }
@@ -913,7 +974,8 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     }
     // a specialised kernel evaluates exactly one program shape in registers and, with a MIX2, keeps its weights out
     // of the bit loop (needs mask 255 and >= 256 weights); anything else -> runtime-loop kernel
-    const bool mix_ok = !cfg->has_mix2 || ((M->comp[M->n - 1].mask & 255) == 255 && M->comp[M->n - 1].c >= 256);
+    const bool mix_ok = !cfg->has_mix2 || ((M->comp[M->n - 1].mask & 255) == 255 && M->comp[M->n - 1].c >= 256 &&
+                                           M->comp[M->n - 1].k == M->n - 2 && M->comp[M->n - 1].j == M->n - 3);
     if (cfg->nch_spec && (!mix_ok || cfg->vm_kind != (cfg->nch_spec == 2 ? zpqc::VM_LEVEL1 : zpqc::VM_HASHCHAIN))) {
         cfg->nch_spec = 0;
         const char *ev = getenv("ZPQ_CHAIN_G");
