@@ -191,10 +191,31 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const int last = n - 1;
     const int nisse_end = NCH ? NCH : cfg.nisse_end;
     const bool has_mix2 = NCH ? MIXT : (cfg.has_mix2 != 0);
-    const int ctype = (li < n) ? M.comp[li].type : 0;
+    // Decode of the short chains (levels 1-2, dense tables): TWO HYPOTHESES per block.  The block's eight lanes are two
+    // copies of the chain -- lanes 0..3 assume the bit being decoded is 0, lanes 4..7 assume it is 1 -- and each copy
+    // does the whole update for ITS outcome (next bit-history state and its table entry, trained weights / counter
+    // with its stretch, the next nibble's row request) while the coder is still working on the bit.  When the bit is
+    // known the copy that guessed right commits its table entry and the other takes over its registers (two DPP
+    // moves per register).  What used to follow the bit in series -- two LDS round trips and ~40 instructions, at
+    // the end of a nibble an HBM round trip -- now runs beside the chain -> squash -> coder path.  Both copies run
+    // the coder (same input, same state), so the bit needs no trip between them.
+#ifdef ZPQ_NO_HYP
+    constexpr bool HYP = false;
+#else
+    constexpr bool HYP = DEC && !SPEC && !SP && !MIXT && (NCH == 2 || NCH == 3) && GG == 8;
+#endif
+    // The other decoders (longer chains, MIX2, line store) have no lanes to spare for a second copy.  They request the
+    // next nibble's rows for BOTH outcomes of the nibble's last bit as soon as its third bit is known -- a whole bit step
+    // before they are needed -- and pick one when they arrive (twice the row reads, no exposed HBM round trip).
+    // (Dense tables without a MIX2 only: with the line store the second probe doubles tag loads and selects, and the
+    //  MIX2 levels have eight tables to fetch twice -- measured slower there: level 5 505 vs 466 ms.)
+    constexpr bool TWO = DEC && !SPEC && !HYP && NCH > 0 && !SP && !MIXT;
+    const int hyp = HYP ? ((li >> 2) & 1) : 0;           // the outcome this lane assumes
+    const int lc = HYP ? (li & 3) : li;                  // the component this lane works for
+    const int ctype = (lc < n) ? M.comp[lc].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
-    const bool is_icm = ctype == ZT_ICM, is_last = li == last;
-    const DComp &C = M.comp[li < n ? li : 0];
+    const bool is_icm = ctype == ZT_ICM, is_last = lc == last;
+    const DComp &C = M.comp[lc < n ? lc : 0];
     // lanes without a hash table (idle, MIX2) run the same row loads against the first 64
     // bytes of the slot: no exec-masked branch around the loads (a branch join would make
     // the compiler wait for them at once and defeat the prefetch); only the store is masked
@@ -216,8 +237,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // in the update phase instead of in front of the prediction chain.  Lanes without a table
     // (idle, MIX2) use per-workgroup dummy tables, so the bit loop needs no role branches.
     u8 *dummy = lds + LDS_STATE + cfg.lds_dummy;
-    u32 *t32 = reinterpret_cast<u32 *>(hashed ? my + cfg.lds_off32[li] : dummy);
-    u8 *t8 = hashed ? my + cfg.lds_off8[li] : dummy + 1024;
+    u32 *t32 = reinterpret_cast<u32 *>(hashed ? my + cfg.lds_off32[lc] : dummy);
+    u8 *t8 = hashed ? my + cfg.lds_off8[lc] : dummy + 1024;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const int mix_j = M.comp[last].j, mix_k = M.comp[last].k, mix_rate = M.comp[last].rate;
     const u32 mix_mask = (u32)M.comp[last].mask, mix_cmask = (u32)(M.comp[last].c - 1);
@@ -299,14 +320,36 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const u32 c = (win0 >> ((vp & 3u) * 8u)) & 255u;
             return pos < nin ? c : 0u;
         };
-        auto in_byte = [&](u32 pos) -> u32 {               // src[pos] for pos in the current/next dword; 0 past the end
+        // Decode consumes 0..4 coded bytes per bit, at positions only the coder knows.  Its window is FOUR dwords,
+        // double-buffered per byte of output: at the top of every byte iteration the window requested one iteration
+        // ago is adopted and the next one (from the coder's current position) is requested, unconditionally -- no load
+        // and no wait inside the bit steps.  (The old two-dword window reloaded inside the renormalisation loop; the
+        // compiler's wait for that load sat at the branch join and was a vmcnt(0): every pass through the loop also
+        // waited for whatever else was in flight -- the row write-back, the next nibble's row request.)  A window
+        // covers what two iterations consume unless the stream expands more than ~6x locally; then one dword is
+        // fetched on the spot.
+        const u32 dlast = ndw ? ndw - 1u : 0u;
+        u32 dW0 = 0, dW1 = 0, dW2 = 0, dW3 = 0, wd = 0;        // dwords [wd, wd + 4) of the coded input
+        u32 nW0 = 0, nW1 = 0, nW2 = 0, nW3 = 0, nwd = 0;       // requested, not yet looked at
+        auto dec_request = [&](const u32 pos) {
+            nwd = (pos + mis) >> 2;
+            nW0 = enc4[min(nwd, dlast)];
+            nW1 = enc4[min(nwd + 1u, dlast)];
+            nW2 = enc4[min(nwd + 2u, dlast)];
+            nW3 = enc4[min(nwd + 3u, dlast)];
+        };
+        auto dec_adopt = [&]() { dW0 = nW0; dW1 = nW1; dW2 = nW2; dW3 = nW3; wd = nwd; };
+        auto in_byte = [&](u32 pos) -> u32 {               // src[pos]; 0 past the end
             const u32 vp = pos + mis;
-            if ((vp >> 2) != wdw) {                        // crossed into win1: slide and prefetch one more dword
-                win0 = win1;
-                wdw++;
-                win1 = (wdw + 1 < ndw) ? src4[wdw + 1] : 0u;
+            const u32 bo = vp - 4u * wd;                   // byte offset inside the 16-byte window
+            // (two 64-bit halves and a 64-bit shift: a four-way select by index gets turned into a scratch array)
+            const u64 lo = (u64)dW0 | ((u64)dW1 << 32), hi = (u64)dW2 | ((u64)dW3 << 32);
+            u32 c = (u32)(((bo & 8u) ? hi : lo) >> ((bo & 7u) * 8u)) & 255u;
+            if (bo > 15u) {
+                u32 t = enc4[min(vp >> 2, dlast)];
+                asm volatile("; coded input beyond the window: waited for here, not at the join" : "+v"(t));
+                c = (t >> ((vp & 3u) * 8u)) & 255u;
             }
-            const u32 c = (win0 >> ((vp & 3u) * 8u)) & 255u;
             return pos < nin ? c : 0u;
         };
 
@@ -316,6 +359,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u32 first = 0xFFFFFFFFu;
         bool got_first = false;
         if (DEC) {
+            dec_request(0u);
+            dec_adopt();
+            dec_request(0u);                               // (adopted by the first byte iteration)
             for (int k = 0; k < 4; k++) { const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c; }
         }
         const u32 total = DEC ? 0xFFFFFFFFu : nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u);
@@ -326,7 +372,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // the stretch an ICM entry carries (meaningless on other lanes, where it is masked out)
         auto icm_st = [](u32 v, i32 b) -> i32 { return (i32)((u32)b << 9) | (i32)(v >> 23); };
         // decoded bit from lane `last` to the lanes below it: log-step DPP row_shl, no LDS round trip
-        const int bdist = last - li;                       // > 0 on lanes that need the value
+        const int bdist = last - lc;                       // > 0 on lanes that need the value
         auto bcast_down = [&](i32 v) -> i32 {
             if constexpr (NCH > 0 && NCH + (MIXT ? 1 : 0) <= 4) {
                 // all of the block's lanes are in one quad: one quad_perm broadcast of the coder lane
@@ -368,40 +414,75 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         bool sp_full = false;
         u32 sp_claims = 0;
         const u32 sp_limit = sp_cap - (sp_cap >> 4);       // a block that needs more than 15/16 of the store is refused
-        auto load_rows = [&](const u32 po) {
-            nA = *reinterpret_cast<const u32x4 *>(tbase + po);
-            nB = *reinterpret_cast<const u32x4 *>(tbase + (po ^ 16u));
-            nC = *reinterpret_cast<const u32x4 *>(tbase + (po ^ 32u));
-        };
-        auto prefetch_rows = [&](const u32 hc, const u32 c8v) {
-            const u32 cx = hc + 16u * c8v;
-            n_chk = (cx >> sizebits) & 255u;
-            const u32 h0 = (cx * 16u) & ht_mask;
-            u32 po = h0;
-            if (SPARSE && sp_cap) {
-                // Dense line index -> slot of the compact store.  Open addressing over GROUPS of four slots: the home
-                // slot is mulhi(hash, cap) (capacity need not be a power of two); probing visits the home group's
-                // slots cyclically from the home slot, then the following groups the same way.  One 16-byte load
-                // brings the home group's four tags, and the HOME slot's rows are fetched with them: a line that
-                // sits in its home slot, or a new line (it takes the first free slot it meets, and a new line is all
-                // zero -- nothing to load), costs one memory round trip; only a line that was displaced when it
-                // was claimed needs a second one for its rows, and only a full group is walked past.
-                n_key = (h0 >> 6) + 1u;
-                n_si = __umulhi(n_key * 0x9E3779B1u, sp_cap);
-                n_off = h0 & 48u;
-                n_tags = *reinterpret_cast<const u32x4 *>(sp_tags + (n_si & ~3u));
-                po = (n_si << 6) + n_off;
-            }
-            n_po = po;
-            load_rows(po);
-        };
+        // second request of the non-HYP decoders (see TWO below): the rows for the other outcome of the nibble's last bit
+        u32x4 aA = {0, 0, 0, 0}, aB = {0, 0, 0, 0}, aC = {0, 0, 0, 0}, a_tags = {0, 0, 0, 0};
+        u32 a_po = 0, a_chk = 0, a_key = 0, a_si = 0, a_off = 0;
+        bool sel_alt = false;                              // the nibble that really follows is the one the alt request was for
+        // (a macro, not a lambda taking references: locals handed on by reference through a second closure are not
+        //  promoted to registers -- the whole probe state ended up in scratch, 5x slower)
+#ifdef ZPQ_DEBUG_NO_ROWS   // timing experiment only (wrong output): no hash-row traffic at all
+#define ZPQ_LOAD_ROWS(A_, B_, C_, po_) do { A_ = u32x4{(po_), 0, 0, 0}; B_ = A_; C_ = A_; } while (0)
+#else
+#define ZPQ_LOAD_ROWS(A_, B_, C_, po_)                                                  \
+    do {                                                                                \
+        A_ = *reinterpret_cast<const u32x4 *>(tbase + (po_));                           \
+        B_ = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 16u));                   \
+        C_ = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 32u));                   \
+    } while (0)
+#endif
+        // Dense line index -> slot of the compact store.  Open addressing over GROUPS of four slots: the home
+        // slot is mulhi(hash, cap) (capacity need not be a power of two); probing visits the home group's
+        // slots cyclically from the home slot, then the following groups the same way.  One 16-byte load
+        // brings the home group's four tags, and the HOME slot's rows are fetched with them: a line that
+        // sits in its home slot, or a new line (it takes the first free slot it meets, and a new line is all
+        // zero -- nothing to load), costs one memory round trip; only a line that was displaced when it
+        // was claimed needs a second one for its rows, and only a full group is walked past.
+#define ZPQ_PREFETCH(A_, B_, C_, tags_, po_, chk_, key_, si_, off_, hc_, c8v_)          \
+    do {                                                                                \
+        const u32 cx_ = (hc_) + 16u * (c8v_);                                           \
+        chk_ = (cx_ >> sizebits) & 255u;                                                \
+        const u32 h0_ = (cx_ * 16u) & ht_mask;                                          \
+        u32 pox_ = h0_;                                                                 \
+        if (SPARSE && sp_cap) {                                                         \
+            key_ = (h0_ >> 6) + 1u;                                                     \
+            si_ = __umulhi(key_ * 0x9E3779B1u, sp_cap);                                 \
+            off_ = h0_ & 48u;                                                           \
+            tags_ = *reinterpret_cast<const u32x4 *>(sp_tags + (si_ & ~3u));            \
+            pox_ = (si_ << 6) + off_;                                                   \
+        }                                                                               \
+        po_ = pox_;                                                                     \
+        ZPQ_LOAD_ROWS(A_, B_, C_, pox_);                                                \
+    } while (0)
+        auto load_rows = [&](const u32 po) { ZPQ_LOAD_ROWS(nA, nB, nC, po); };
+        auto prefetch_rows = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(nA, nB, nC, n_tags, n_po, n_chk, n_key, n_si, n_off, hc, c8v); };
+        auto prefetch_alt = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(aA, aB, aC, a_tags, a_po, a_chk, a_key, a_si, a_off, hc, c8v); };
         // Consume the rows requested one nibble ago, THEN write the finished row back (so that
         // the wait for the loads does not also wait for a just-issued store), then the caller
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
         // is one of the candidates.
+        // two-hypothesis decode: the same register of the block's OTHER copy (lane ^ 4): lanes 0..3 of each eight take
+        // from four lanes up, lanes 4..7 from four lanes down (bank masks 0101 / 1010 of a 16-lane DPP row)
+        auto xchg = [&](const u32 v) -> u32 {
+            u32 t = (u32)__builtin_amdgcn_update_dpp((i32)v, (i32)v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+            t = (u32)__builtin_amdgcn_update_dpp((i32)t, (i32)v, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+            return t;
+        };
+        bool row_mine = true;                              // this copy requested the rows of the nibble that really follows
         auto take_prefetched = [&](const bool have_prev) {
             bool claim = false;
             u32 claim_si = 0;
+            if (TWO) {                                         // (selects, not a branch: both requests are waited for here anyway)
+                auto sel4 = [](const bool c, const u32x4 a, const u32x4 b) -> u32x4 {
+                    return u32x4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
+                };
+                nA = sel4(sel_alt, aA, nA); nB = sel4(sel_alt, aB, nB); nC = sel4(sel_alt, aC, nC);
+                n_po = sel_alt ? a_po : n_po; n_chk = sel_alt ? a_chk : n_chk;
+                if (SPARSE) {
+                    n_tags = sel4(sel_alt, a_tags, n_tags);
+                    n_key = sel_alt ? a_key : n_key; n_si = sel_alt ? a_si : n_si; n_off = sel_alt ? a_off : n_off;
+                }
+                sel_alt = false;
+            }
             if (SPARSE && sp_cap) {
                 const u32 o = n_si & 3u;
                 // slots of a group that end the probe -- the line's own tag, or a free slot -- as a 4-bit mask rotated
@@ -448,6 +529,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const bool fc = have_prev && (n_po ^ 32u) == poff;
             const u32x4 A = fa ? Rp : nA, Bq = fb ? Rp : nB, Cq = fc ? Rp : nC;
             select_row(A, Bq, Cq, n_po, n_chk);
+            if constexpr (HYP) {
+                // each copy asked for the rows of ITS outcome; the one that was wrong takes the other's resolved row
+                const u32 x0 = xchg(X.r0), x1 = xchg(X.r1), x2 = xchg(X.r2), x3 = xchg(X.r3), xo = xchg(roff);
+                X.r0 = row_mine ? X.r0 : x0; X.r1 = row_mine ? X.r1 : x1; X.r2 = row_mine ? X.r2 : x2; X.r3 = row_mine ? X.r3 : x3;
+                roff = row_mine ? roff : xo;
+            }
             // keep the stores BELOW the wait for the loads above (vmcnt is in-order: a store issued
             // first would be waited for as well)
             u32 poff2 = poff, cpo = n_po & ~63u;
@@ -461,10 +548,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 *reinterpret_cast<u32x4 *>(line + 32) = z4;
                 *reinterpret_cast<u32x4 *>(line + 48) = z4;
             }
-            if (have_prev && hashed) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;
+#ifndef ZPQ_DEBUG_NO_ROWS
+            if (have_prev && hashed && (!HYP || hyp == 0)) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;   // (both copies hold the same row)
+#endif
         };
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
-        auto run_vm = [&](const u32 byte) -> u32 {
+        // vm_hash: the contexts a byte leads to, WITHOUT touching the VM's state (the two-hypothesis decoder asks for a
+        // byte that may not be the one decoded); vm_commit: the state change once the byte is certain.
+        auto vm_hash = [&](const u32 byte) -> u32 {
             u32 hv = 0;
             // the specialised kernels are only launched for their level's own program shape (chain of 2 = level 1's
             // program, longer chains = the hash chain): the interpreter and its state exist only in the runtime-loop kernel
@@ -472,18 +563,51 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             if (vm_kind == VM_HASHCHAIN) {
                 // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
                 u32 a = byte;
-                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == li) ? a : hv; }
-                prev = byte;
+                for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == lc) ? a : hv; }
             } else if (vm_kind == VM_LEVEL1) {
                 // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
-                m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                const u32 mm = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+                u32 bb = b4;
                 u32 a = 0;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                const u32 h0v = a; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u; b4--;
-                a = (a + ((m4 >> ((b4 & 3) * 8)) & 255u) + 512u) * 773u;
-                hv = (li == 0) ? h0v : ((li == 1) ? a : 0u);
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+                const u32 h0v = a; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+                a = (a + ((mm >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+                hv = (lc == 0) ? h0v : ((lc == 1) ? a : 0u);
+            }
+            return hv;
+        };
+        auto vm_commit = [&](const u32 byte) {
+            const int vm_kind = NCH == 0 ? cfg.vm_kind : (NCH == 2 ? (int)VM_LEVEL1 : (int)VM_HASHCHAIN);
+            if (vm_kind == VM_HASHCHAIN) prev = byte;
+            else if (vm_kind == VM_LEVEL1) { m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8)); b4 -= 3u; }
+        };
+        // Encode: coded bytes are queued in a register pair and stored at ONE fixed point per input byte, right behind
+        // the wait for the first nibble's rows.  A byte store issued inside the coder would be the youngest memory
+        // operation when the next row wait comes, and vmcnt retires in order: the wait would sit out the store.
+        u64 oq = 0;
+        u32 oqn = 0;                                       // queued bytes (they end at X.opos)
+        auto oq_flush = [&]() {
+            const u32 base = X.opos - oqn;
+            for (u32 k = 0; k < oqn; k++) {
+                if (base + k < cap) dst[base + k] = (u8)(oq >> (8u * k));
+            }
+            oq = 0; oqn = 0;
+        };
+        auto put_byte = [&](const u32 b) {                 // Writer.put (encoder.v:76-83)
+            oq |= (u64)(b & 255u) << (8u * oqn);
+            oqn++;
+            X.opos++;
+            if (oqn == 8u) oq_flush();
+        };
+        // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
+        auto run_vm = [&](const u32 byte) -> u32 {
+            u32 hv = 0;
+            const int vm_kind = NCH == 0 ? cfg.vm_kind : (NCH == 2 ? (int)VM_LEVEL1 : (int)VM_HASHCHAIN);
+            if (vm_kind == VM_HASHCHAIN || vm_kind == VM_LEVEL1) {
+                hv = vm_hash(byte);
+                vm_commit(byte);
             } else {
                 if (li == 0) { if (!vm_run(z, byte)) status = ZPQ_E_VMSTEPS; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -591,6 +715,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         i32 pin_cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // its predecessor's predictions for that byte
         i32 pj_cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // MIX2 lane: the predecessor's input (= p[j])
 
+        u32 hn_main = 0, hn_alt = 0;                       // TWO: the next byte's context hash for last bit 0 / 1
         auto bitstep = [&](auto kc, auto nbc) {
             constexpr int K = decltype(kc)::value;
             constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;   // bit of the byte this step codes (7..0)
@@ -622,7 +747,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             auto chain_step = [&](const int i) {
                 const i32 pv = row_shr1(p);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
-                const bool me = li == i;
+                const bool me = lc == i;
                 pin = me ? pv : pin;
                 p = me ? pn : p;
             };
@@ -689,18 +814,22 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 X.high = y ? mid : X.high;
                 X.low = y ? X.low : mid + 1;
                 while ((X.high ^ X.low) < 0x1000000u) {
-                    if (!DEC) { if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24); X.opos++; }
+                    if (!DEC) put_byte(X.high >> 24);
                     X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
                     if (DEC) { const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c; }
                 }
             }
             if (DEC) y = bcast_down(y);
-            if (DEC && K == 3) {
+            if (DEC && K == 3 && !TWO) {
                 // the nibble's last bit is known: request the next nibble's rows now, so that their
                 // latency overlaps this bit's update work (contexts: predictor.v:558-560,809-816)
                 const u32 c8n = (X.c8 << 1) | (u32)y;
                 if (bit == 4) prefetch_rows(hctx, c8n);
                 else { hnext_dec = run_vm(c8n - 256u); prefetch_rows(hnext_dec, 1u); }
+            }
+            if (DEC && K == 3 && TWO) {
+                sel_alt = y != 0;
+                if (bit == 0) { hnext_dec = y ? hn_alt : hn_main; vm_commit(((X.c8 << 1) | (u32)y) - 256u); }
             }
             // ---- (4b) plain form: the bit is known, so is the next slot (2*slot + y).  Fetch the next bit's
             //           entry NOW, before this bit's update is computed and stored -- otherwise the read
@@ -773,6 +902,121 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             else { X.r3 = (X.slot & 4u) ? ins : X.r3; X.r2 = (X.slot & 4u) ? X.r2 : ins; }
             X.c8 = (X.c8 << 1) | (u32)y;
             X.slot = (K == 3) ? 1u : (X.slot * 2u + (u32)y);
+            if (TWO && K == 2) {
+                // three bits of the nibble are known: request the next nibble's rows for both values of the fourth
+                const u32 c8n = X.c8 << 1;
+                if (bit == 5) { prefetch_alt(hctx, c8n | 1u); prefetch_rows(hctx, c8n); }
+                else {
+                    hn_main = vm_hash(c8n - 256u);
+                    hn_alt = vm_hash((c8n | 1u) - 256u);
+                    prefetch_alt(hn_alt, 1u);
+                    prefetch_rows(hn_main, 1u);
+                }
+            }
+        };
+
+        // Two-hypothesis decode step (see HYP above).  Program order = what may run beside what: the chain and the
+        // squash request first; then everything this copy can do for ITS assumed bit yh without the squash value
+        // (next state and its entry, the counter's next value and its stretch, the next nibble's rows); then the
+        // squash-dependent training; then the coder; then commit / take-over.
+        u32 hn_spec = 0;                                   // next byte's context hash under this copy's outcome of the last bit
+        auto bitstep_hyp = [&](auto kc, auto nbc) {
+            constexpr int K = decltype(kc)::value;
+            constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;
+            const u32 s = cur_s;
+            const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);
+            const u32 cmv = cur_v & 0x7FFFFFu;
+            const i32 w0 = ((i32)(cur_v << 12)) >> 12;
+            const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
+            i32 p = is_icm ? cur_pst : 0, pin = 0;
+#pragma unroll
+            for (int i = 1; i < (NCH ? NCH : 1); i++) {
+                const i32 pv = row_shr1(p);
+                const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);
+                const bool me = lc == i;
+                pin = me ? pv : pin;
+                p = me ? pn : p;
+            }
+            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+            // ---- this copy's outcome
+            const i32 yh = hyp;
+            u32 sN = 0, rNv = 0;
+            i32 rNb = 0;
+            if (K < 3) {
+                u32 pair;
+                if (K == 0) pair = X.r0 >> 16;
+                else if (K == 1) pair = X.r1 >> ((X.slot & 1u) * 16u);
+                else pair = ((X.slot & 2u) ? X.r3 : X.r2) >> ((X.slot & 1u) * 16u);
+                sN = yh ? ((pair >> 8) & 255u) : (pair & 255u);
+                rNv = t32[sN];
+                rNb = (i32)(int8_t)t8[sN];
+            }
+            const u32 cmn = (u32)wadd((i32)cmv, ((yh ? 32767 : 0) - (i32)(cmv >> 8)) >> 2);
+            const i32 st_new = stretch_of(cmn);
+            const i32 err = (yh ? 32767 : 0) - sq;
+            const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
+            const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
+            const u32 nv = is_icm ? (cmn | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
+            const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
+            u32 nxt_v = 0, nxt_bs = 0;
+            if (K < 3) {
+                const bool same = sN == s;
+                nxt_v = same ? nv : rNv;
+                nxt_bs = ((u32)(same ? nb : rNb) & 255u) | (sN << 8);
+            }
+            // ---- the bit (both copies decode it: same code, same window, same bounds)
+            i32 y = 0;
+            if (is_last) {
+                const u32 p16 = (u32)sq * 2u + 1u;
+                const u32 mid = X.low + (u32)(((u64)(X.high - X.low) * p16) >> 16);
+                y = X.code <= mid ? 1 : 0;
+                X.high = y ? mid : X.high;
+                X.low = y ? X.low : mid + 1;
+                while ((X.high ^ X.low) < 0x1000000u) {
+                    X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
+                    const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c;
+                }
+            }
+            y = bcast_down(y);
+            // ---- commit / take over
+            const bool mine = y == yh;
+            if (mine) { t32[s] = nv; t8[s] = (u8)nb; }          // one copy trains the (shared) table entry
+            if (K < 3) {
+                const u32 xv = xchg(nxt_v), xb = xchg(nxt_bs);
+                cur_v = mine ? nxt_v : xv;
+                const u32 bs = mine ? nxt_bs : xb;
+                cur_b = (i32)(int8_t)(bs & 255u);
+                cur_s = bs >> 8;
+                cur_pst = icm_st(cur_v, cur_b);
+            } else {
+                row_mine = mine;
+                if (bit == 0) {
+                    const u32 xh = xchg(hn_spec);
+                    hnext_dec = mine ? hn_spec : xh;
+                    vm_commit(((X.c8 << 1) | (u32)y) - 256u);
+                }
+            }
+            // next bit-history state into the row (statetable.v:75-84), with the decoded bit
+            const u32 nsv = y ? (ns01 >> 8) : (ns01 & 255u);
+            const u32 sh = (X.slot & 3u) * 8u;
+            const u32 dsel = (K <= 1) ? X.r0 : (K == 2 ? X.r1 : ((X.slot & 4u) ? X.r3 : X.r2));
+            const u32 ins = (dsel & ~(255u << sh)) | (nsv << sh);
+            if (K <= 1) X.r0 = ins;
+            else if (K == 2) X.r1 = ins;
+            else { X.r3 = (X.slot & 4u) ? ins : X.r3; X.r2 = (X.slot & 4u) ? X.r2 : ins; }
+            X.c8 = (X.c8 << 1) | (u32)y;
+            X.slot = (K == 3) ? 1u : (X.slot * 2u + (u32)y);
+            if (K == 2) {
+                // Three bits of the nibble are known: this copy asks for the rows of the next nibble under ITS outcome of
+                // the fourth.  The request has the whole last bit step (~1000 cycles) to travel before it is needed;
+                // the HBM round trip measured here is ~1350 cycles.
+                const u32 c8n = (X.c8 << 1) | (u32)hyp;
+                if (bit == 5) prefetch_rows(hctx, c8n);
+                else { hn_spec = vm_hash(c8n - 256u); prefetch_rows(hn_spec, 1u); }
+            }
+        };
+        auto step = [&](auto kc, auto nbc) {
+            if constexpr (HYP) bitstep_hyp(kc, nbc); else bitstep(kc, nbc);
         };
 
         // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
@@ -786,6 +1030,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // moves when the iteration ends.  Inside an iteration no lane waits for another: the per-bit dependent chain
         // ICM -> ISSE -> ... -> coder (one DPP + multiply + clamp per link, in series) becomes one link per bit.
         // The coder stays on the last component's lane and so sees bytes in order; it - c < 0 or >= total: lane idle.
+        bool pend_store = false;                           // decode: the last decoded byte still has to be stored
+        u32 pend_pos = 0, pend_val = 0;
         const u32 skew_delay = SKEW ? (u32)li : 0u;
         const u32 iters = SKEW ? total + (u32)last : total;
         for (u32 it = 0; it < iters; it++) {
@@ -793,6 +1039,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             // (lanes beyond the last component stay in step on dummy tables: masking them off made level 1 30 % slower --
             //  measured 286 vs 219 ms, cause not understood)
             if (!SKEW || bi < total) {
+            if (DEC) { dec_adopt(); dec_request(X.ipos); }
             if (!DEC) {
                 const u32 cpos = (B.flags & ZPQ_FLAG_PP) ? bi - 1u : bi;
                 const u32 cb = enc_byte((B.flags & ZPQ_FLAG_PP) && bi == 0 ? 0u : cpos);
@@ -803,8 +1050,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 if (is_last) {
                     X.low += 1;                               // p=0, y=0: mid = low, low = mid+1
                     while ((X.high ^ X.low) < 0x1000000u) {
-                        if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24);
-                        X.opos++;
+                        put_byte(X.high >> 24);
                         X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
                     }
                 }
@@ -825,6 +1071,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             X.c8 = 1; X.slot = 1;
             u32 hnext = 0;
             take_prefetched(bi != 0);                         // rows of this byte's first nibble
+            if (DEC && pend_store) { dst[pend_pos] = (u8)pend_val; pend_store = false; }   // (see pend_store)
+            if (!DEC && is_last) oq_flush();
             if (DEC && mixreg) mixw_arrive();
             if (!DEC && mixreg) mix_byte_begin(ch, bi != 0);  // (before the prefetch below, see mix_byte_begin)
             if (!DEC) {
@@ -832,25 +1080,29 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 prefetch_rows(hctx, 16u | (ch >> 4));         // second nibble of this byte, a nibble ahead
             }
             nibble_begin();
-            bitstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            bitstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-            bitstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-            bitstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
             take_prefetched(true);
             if (DEC && mixreg) mixw_arrive();
             if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();
-            bitstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-            bitstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-            bitstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
-            bitstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
             const u32 byte = X.c8 - 256;
             hctx = DEC ? hnext_dec : hnext;
 
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
                 else {
-                    if (is_last && X.opos < cap) dst[X.opos] = (u8)byte;
+                    // The byte is STORED behind the next iteration's wait for its rows: a store issued here would be
+                    // the youngest memory operation when that wait comes, and vmcnt retires in order.
+                    pend_store = is_last && hyp == 0 && X.opos < cap;                 // (one copy writes)
+                    pend_pos = X.opos;
+                    pend_val = byte;
                     X.opos++;                                 // uniform across the group when decoding
                     if (X.opos > cap) break;
                 }
@@ -867,23 +1119,21 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
         }
 
+        if (DEC && pend_store) dst[pend_pos] = (u8)pend_val;
         // (the last nibble's row is not written back: the slot is re-initialised for the next block)
         // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
         if (!DEC && is_last) {
             X.high = X.low;                                   // encode(1, 0): mid = low, high = mid
             while ((X.high ^ X.low) < 0x1000000u) {
-                if (X.opos < cap) dst[X.opos] = (u8)(X.high >> 24);
-                X.opos++;
+                put_byte(X.high >> 24);
                 X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
             }
-            for (int sft = 24; sft >= 0; sft -= 8) {
-                if (X.opos < cap) dst[X.opos] = (u8)(X.high >> sft);
-                X.opos++;
-            }
+            for (int sft = 24; sft >= 0; sft -= 8) put_byte(X.high >> sft);
+            oq_flush();
         }
         i32 st0 = row_bcast(status, row_base);                 // VM status lives on lane 0
         for (int c = 1; c < n; c++) { const i32 sc = row_bcast(status, row_base + c); st0 = st0 ? st0 : sc; }   // line-store overflow: any hashed lane
-        if (is_last) {
+        if (is_last && hyp == 0) {
             i32 st = st0;
             if (X.opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
             B.out_len[blk] = X.opos;
