@@ -121,6 +121,30 @@ int zpq_decode_blocks(zpq_ctx *, const zpq_model *, int nblocks, const uint8_t *
                       const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
                       uint32_t *final_code, uint32_t *first_byte, int32_t *status);
 
+/*
+ * Host-pointer batches are worked off in rounds of at most the resident capacity; the upload of round
+ * r+1 and the download of round r-1 run beside the coding of round r (three streams).  Buffers from
+ * zpq_host_alloc (pinned, device-visible) make the transfers plain DMA and let the GPU pack each block's
+ * produced bytes straight into the caller's slab -- only bytes that exist cross PCIe.  Pageable buffers
+ * work too (staged copies by the runtime, whole slabs come back).  One slab may be at most 4 GiB - 16.
+ */
+void *zpq_host_alloc(size_t bytes);
+void zpq_host_free(void *);
+
+/*
+ * The same batch dealt over several contexts (one per GPU; several on one GPU also work): context g
+ * codes the g-th contiguous share of the blocks on its own host thread.  Replaces the reference's
+ * single-threaded loop over files (cmd/main.v:283-311; its -threads option is parsed and dropped,
+ * cmd/main.v:35,97,156).  Blocks are independent, so the result is bit-identical for any nctx.
+ */
+int zpq_encode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *, int nblocks, const uint8_t *in,
+                            const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
+                            uint32_t *out_len, int32_t *status);
+int zpq_decode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *, int nblocks, const uint8_t *in,
+                            const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
+                            uint32_t *out_len, uint32_t *consumed, uint32_t *final_code, uint32_t *first_byte,
+                            int32_t *status);
+
 /* Same, but every pointer is a DEVICE pointer and the call only enqueues work on
  * the ctx stream (no host sync, no PCIe).  This is the form bench.py times.
  * Ordering contract: the ctx stream is created hipStreamNonBlocking, so it does NOT

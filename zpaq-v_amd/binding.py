@@ -64,6 +64,11 @@ def lib():
     L.zpq_encode_blocks_dev.argtypes = enc
     L.zpq_decode_blocks.argtypes = dec
     L.zpq_decode_blocks_dev.argtypes = dec
+    L.zpq_host_alloc.argtypes = [C.c_size_t]
+    L.zpq_host_alloc.restype = vp
+    L.zpq_host_free.argtypes = [vp]
+    L.zpq_encode_blocks_multi.argtypes = [vp, i32, vp, i32, vp, vp, u32, vp, vp, vp, vp]
+    L.zpq_decode_blocks_multi.argtypes = [vp, i32, vp, i32, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.zpq_sha1_blocks.argtypes = [vp, i32, vp, vp, vp]
     L.zpq_sha1_blocks_dev.argtypes = [vp, i32, vp, vp, vp]
     L.zpq_sha1_ranges_dev.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -136,6 +141,26 @@ class Model:
     @property
     def has_fast_path(self):
         return bool(lib().zpq_model_has_fast_path(self.h))
+
+
+class PinnedArray:
+    """A numpy view over page-locked, device-visible host memory (zpq_host_alloc): what a front end should hand
+    to the host-pointer batch calls so that transfers are plain DMA and outputs are packed by the GPU."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().zpq_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise ZpqError(-6, "zpq_host_alloc")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def free(self):
+        if getattr(self, "ptr", None) and _LIB is not None:
+            self.array = None
+            _LIB.zpq_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 def _offsets(lengths):

@@ -18,6 +18,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/zpaq_hip.h"
@@ -97,6 +98,30 @@ struct zpq_ctx {
     const char *last_name = "";
     // staging for the host-pointer entry points
     DevBuf s_in, s_out, s_inoff, s_outoff, s_u32[4], s_status, s_misc;
+    // pipelined host batches (host_pipeline): two staging sets, a copy-in and a copy-out stream beside the compute stream
+    struct PipeSet {
+        DevBuf in, out, inoff, outoff, dstoff, meta, status;
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+        // pinned host side of the small arrays: a copy to or from PAGEABLE memory blocks the calling thread until it
+        // has run, i.e. until the round's kernel is done -- which would keep the next round's upload from being queued
+        uint64_t *h_off = nullptr;         // [3][n + 1]: relative in / out offsets, absolute destination offsets
+        uint32_t *h_meta = nullptr;        // [4][n] out_len, consumed, final_code, first_byte  + [n] status
+        size_t h_cap = 0;                  // blocks the pinned arrays are sized for
+        int b0 = 0, n = 0;                 // the round whose results sit in h_meta (not yet handed to the caller)
+        int ensure_host(size_t nblk)
+        {
+            if (nblk <= h_cap) return ZPQ_OK;
+            if (h_off) (void)hipHostFree(h_off);
+            if (h_meta) (void)hipHostFree(h_meta);
+            h_off = nullptr; h_meta = nullptr; h_cap = 0;
+            const size_t want = nblk + nblk / 8 + 16;
+            if (hipHostMalloc((void **)&h_off, 3 * (want + 1) * 8, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&h_meta, 5 * want * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ZPQ_E_NOMEM; }
+            h_cap = want;
+            return ZPQ_OK;
+        }
+    } pipe[2];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::mutex mu;
 };
 
@@ -144,6 +169,13 @@ static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
     HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCK(hipEventCreate(&c->ev0));
     HIPCK(hipEventCreate(&c->ev1));
+    HIPCK(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    for (auto &ps : c->pipe) {
+        HIPCK(hipEventCreateWithFlags(&ps.ev_in, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&ps.ev_k, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&ps.ev_out, hipEventDisableTiming));
+    }
     // device tables: squash/stretch/dt2k narrowed to i16 (all values fit)
     std::vector<int16_t> sq(4096), st(32768), d2(256);
     for (int i = 0; i < 4096; i++) sq[i] = (int16_t)T.squash[i];
@@ -183,6 +215,16 @@ extern "C" void zpq_ctx_destroy(zpq_ctx *c)
     c->s_in.release(); c->s_out.release(); c->s_inoff.release(); c->s_outoff.release();
     for (auto &b : c->s_u32) b.release();
     c->s_status.release(); c->s_misc.release();
+    for (auto &ps : c->pipe) {
+        ps.in.release(); ps.out.release(); ps.inoff.release(); ps.outoff.release(); ps.dstoff.release(); ps.meta.release(); ps.status.release();
+        if (ps.h_off) (void)hipHostFree(ps.h_off);
+        if (ps.h_meta) (void)hipHostFree(ps.h_meta);
+        if (ps.ev_in) (void)hipEventDestroy(ps.ev_in);
+        if (ps.ev_k) (void)hipEventDestroy(ps.ev_k);
+        if (ps.ev_out) (void)hipEventDestroy(ps.ev_out);
+    }
+    if (c->s_h2d) { (void)hipStreamSynchronize(c->s_h2d); (void)hipStreamDestroy(c->s_h2d); }
+    if (c->s_d2h) { (void)hipStreamSynchronize(c->s_d2h); (void)hipStreamDestroy(c->s_d2h); }
     (void)hipFree(c->d_squash); (void)hipFree(c->d_stretch); (void)hipFree(c->d_dt2k);
     (void)hipFree(c->d_dt); (void)hipFree(c->d_ns); (void)hipFree(c->d_stretch_c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -423,6 +465,9 @@ extern "C" int zpq_decode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks
 }
 
 // ------------------------------------------------------------------ host-pointer forms
+static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, const uint8_t *in, const uint64_t *in_off,
+                         uint32_t flags, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
+                         uint32_t *final_code, uint32_t *first_byte, int32_t *status);
 static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, const uint8_t *in,
                       const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
                       uint32_t *out_len, uint32_t *consumed, uint32_t *final_code,
@@ -440,6 +485,8 @@ static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, c
     if ((in_bytes && !in) || (out_bytes && !out)) return ZPQ_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCK(hipSetDevice(c->device));
+    if (nblocks >= 2 && !own_slot && !trace && !ctx_out)
+        return host_pipeline(c, m, decode, nblocks, in, in_off, flags, out, out_off, out_len, consumed, final_code, first_byte, status);
     int rc;
     const size_t offb = (size_t)(nblocks + 1) * 8, u32b = (size_t)nblocks * 4;
     if ((rc = c->s_in.ensure(in_bytes + 16)) || (rc = c->s_out.ensure(out_bytes + 16)) ||
@@ -487,6 +534,126 @@ static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, c
     return ZPQ_OK;
 }
 
+// ------------------------------------------------------------------ pinned host memory + pipelined host batches
+extern "C" void *zpq_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void zpq_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// device-visible address of a host buffer if it is pinned (zpq_host_alloc / hipHostMalloc / hipHostRegister), else null
+static void *pinned_device_ptr(const void *p)
+{
+    if (!p) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+}
+
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
+                                                uint8_t *dst, const uint64_t *dst_off, int n);
+
+// Batches of two or more blocks through host pointers, in ROUNDS of at most the resident capacity: round r+1 is
+// uploaded and round r-1 downloaded while round r is coded (three streams, two staging sets).  What replaces the
+// reference's sequential loop over files (cmd/main.v:283-311: read, compress, write, next file) keeps that order per
+// block but moves the three phases of different rounds in parallel.  With PINNED caller buffers (zpq_host_alloc)
+// uploads are plain DMA and the output is packed by the GPU straight into the caller's slabs -- only bytes that
+// were produced cross PCIe; with pageable buffers the runtime's staged copies are used and whole slabs come back.
+static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, const uint8_t *in, const uint64_t *in_off,
+                         uint32_t flags, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
+                         uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+{
+    HIPCK(hipSetDevice(c->device));
+    Plan P0;
+    int rc = plan_batch(c, m, flags, nblocks, false, false, &P0);
+    if (rc != ZPQ_OK) return rc;
+    // Rounds only where overlapping transfers with coding can pay: a batch that exceeds the resident capacity AND
+    // moves a sizeable amount of data.  Smaller batches go as one launch (blocks beyond the capacity are worked off
+    // by the resident groups in turn, inside the kernel).
+    uint64_t min_bytes = 64ull << 20;
+    if (const char *ev = getenv("ZPQ_PIPE_MIN_BYTES")) min_bytes = strtoull(ev, nullptr, 0);   // tests: force rounds on small data
+    const bool big = in_off[nblocks] - in_off[0] + out_off[nblocks] - out_off[0] >= min_bytes;
+    const int per_round = (big && P0.nslots > 0) ? P0.nslots : nblocks;
+    uint8_t *const out_dev_view = (uint8_t *)pinned_device_ptr(out);           // non-null: the GPU can write the caller's slabs
+    const bool in_pinned = pinned_device_ptr(in) != nullptr;
+    (void)in_pinned;                                                            // (hipMemcpyAsync takes either kind; pinned = true DMA)
+    const int nrounds = (nblocks + per_round - 1) / per_round;
+    // hand a finished round's small results (in the set's pinned arrays) to the caller's arrays
+    auto deliver = [&](zpq_ctx::PipeSet &S) {
+        if (!S.n) return;
+        const size_t nn = (size_t)S.n;
+        memcpy(out_len + S.b0, S.h_meta, nn * 4);
+        if (decode && consumed) memcpy(consumed + S.b0, S.h_meta + nn, nn * 4);
+        if (decode && final_code) memcpy(final_code + S.b0, S.h_meta + 2 * nn, nn * 4);
+        if (decode && first_byte) memcpy(first_byte + S.b0, S.h_meta + 3 * nn, nn * 4);
+        memcpy(status + S.b0, S.h_meta + 4 * nn, nn * 4);
+        S.n = 0;
+    };
+    c->pipe[0].n = c->pipe[1].n = 0;
+    for (int r = 0; r < nrounds; r++) {
+        zpq_ctx::PipeSet &S = c->pipe[r & 1];
+        const int b0 = r * per_round, b1 = (b0 + per_round < nblocks) ? b0 + per_round : nblocks, n = b1 - b0;
+        if (r >= 2) { HIPCK(hipEventSynchronize(S.ev_out)); deliver(S); }       // the set's previous round has left the device
+        const uint64_t in_base = in_off[b0], in_bytes = in_off[b1] - in_base;
+        const uint64_t out_base = out_off[b0], out_bytes = out_off[b1] - out_base;
+        const size_t offb = (size_t)(n + 1) * 8, u32b = (size_t)n * 4;
+        if ((rc = S.in.ensure(in_bytes + 16)) || (rc = S.out.ensure(out_bytes + 16)) || (rc = S.inoff.ensure(offb)) ||
+            (rc = S.outoff.ensure(offb)) || (rc = S.dstoff.ensure(offb)) || (rc = S.meta.ensure(u32b * 4)) || (rc = S.status.ensure(u32b)) ||
+            (rc = S.ensure_host((size_t)n)))
+            return rc;
+        uint64_t *h_in = S.h_off, *h_out = S.h_off + (n + 1), *h_dst = S.h_off + 2 * (size_t)(n + 1);
+        for (int k = 0; k <= n; k++) { h_in[k] = in_off[b0 + k] - in_base; h_out[k] = out_off[b0 + k] - out_base; h_dst[k] = out_off[b0 + k]; }
+        // ---- upload on the copy-in stream
+        if (in_bytes) HIPCK(hipMemcpyAsync(S.in.p, in + in_base, in_bytes, hipMemcpyHostToDevice, c->s_h2d));
+        HIPCK(hipMemcpyAsync(S.inoff.p, h_in, offb, hipMemcpyHostToDevice, c->s_h2d));
+        HIPCK(hipMemcpyAsync(S.outoff.p, h_out, offb, hipMemcpyHostToDevice, c->s_h2d));
+        HIPCK(hipMemcpyAsync(S.dstoff.p, h_dst, offb, hipMemcpyHostToDevice, c->s_h2d));
+        HIPCK(hipMemsetAsync(S.status.p, 0xff, u32b, c->s_h2d));              // -1: "kernel never reported"
+        HIPCK(hipMemsetAsync(S.meta.p, 0, u32b * 4, c->s_h2d));
+        HIPCK(hipEventRecord(S.ev_in, c->s_h2d));
+        // ---- code on the compute stream
+        HIPCK(hipStreamWaitEvent(c->stream, S.ev_in, 0));
+        uint32_t *d_len = (uint32_t *)S.meta.p, *d_cons = d_len + n, *d_code = d_cons + n, *d_first = d_code + n;
+        BatchArgs a;
+        memset(&a, 0, sizeof a);
+        a.nblocks = n; a.in = (const uint8_t *)S.in.p; a.in_off = (const uint64_t *)S.inoff.p; a.flags = flags;
+        a.out = (uint8_t *)S.out.p; a.out_off = (const uint64_t *)S.outoff.p; a.out_len = d_len;
+        a.consumed = decode ? d_cons : nullptr; a.final_code = decode ? d_code : nullptr; a.first_byte = decode ? d_first : nullptr;
+        a.status = (int32_t *)S.status.p;
+        rc = run_batch(c, m, decode, a);
+        if (rc != ZPQ_OK) { (void)hipDeviceSynchronize(); return rc; }
+        HIPCK(hipEventRecord(S.ev_k, c->stream));
+        // ---- download on the copy-out stream
+        HIPCK(hipStreamWaitEvent(c->s_d2h, S.ev_k, 0));
+        HIPCK(hipMemcpyAsync(S.h_meta, d_len, u32b * 4, hipMemcpyDeviceToHost, c->s_d2h));
+        HIPCK(hipMemcpyAsync(S.h_meta + 4 * (size_t)n, S.status.p, u32b, hipMemcpyDeviceToHost, c->s_d2h));
+        S.b0 = b0; S.n = n;
+        if (out_bytes) {
+            if (out_dev_view) {
+                // the GPU packs each block's produced bytes straight into the caller's (pinned) slab
+                hipLaunchKernelGGL(k_gather, dim3(n), dim3(256), 0, c->s_d2h, (const uint8_t *)S.out.p, (const uint64_t *)S.outoff.p,
+                                   (const uint32_t *)d_len, out_dev_view, (const uint64_t *)S.dstoff.p, n);
+                HIPCK(hipGetLastError());
+            } else {
+                // pageable destination: the runtime stages this copy and the call returns only when it has run, so
+                // with pageable slabs rounds do not overlap (use zpq_host_alloc)
+                HIPCK(hipMemcpyAsync(out + out_base, S.out.p, out_bytes, hipMemcpyDeviceToHost, c->s_d2h));
+            }
+        }
+        HIPCK(hipEventRecord(S.ev_out, c->s_d2h));
+    }
+    HIPCK(hipStreamSynchronize(c->s_d2h));
+    HIPCK(hipStreamSynchronize(c->stream));
+    deliver(c->pipe[nrounds & 1]);                                             // (older round first)
+    deliver(c->pipe[(nrounds + 1) & 1]);
+    return ZPQ_OK;
+}
+
 extern "C" int zpq_encode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
                                  const uint64_t *in_off, uint32_t flags, uint8_t *out,
                                  const uint64_t *out_off, uint32_t *out_len, int32_t *status)
@@ -502,6 +669,49 @@ extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, co
 {
     return host_batch(c, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed,
                       final_code, first_byte, status, nullptr, nullptr, 0, nullptr, 0);
+}
+
+// ------------------------------------------------------------------ several GPUs behind one call
+// Blocks are independent (compressor.v:90,147-148: fresh Predictor/ZPAQL per block), so any static deal gives the same
+// bytes.  Context g takes the g-th contiguous share -- contiguous so that its PCIe transfers are -- on its own host
+// thread (one host thread per device, no cross-device step but the caller's own buffers).
+static int multi_batch(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int decode, int nblocks, const uint8_t *in,
+                       const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                       uint32_t *consumed, uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+{
+    if (!ctxs || nctx <= 0 || !m || nblocks < 0) return ZPQ_E_ARG;
+    for (int g = 0; g < nctx; g++) if (!ctxs[g]) return ZPQ_E_ARG;
+    if (nblocks == 0) return ZPQ_OK;
+    if (!in_off || !out_off || !out_len || !status) return ZPQ_E_ARG;
+    const int G = nctx < nblocks ? nctx : nblocks;
+    std::vector<int> rcs((size_t)G, ZPQ_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; g++) {
+        const int b0 = (int)((int64_t)nblocks * g / G), b1 = (int)((int64_t)nblocks * (g + 1) / G);
+        th.emplace_back([=, &rcs]() {
+            rcs[(size_t)g] = host_batch(ctxs[g], m, decode, b1 - b0, in, in_off + b0, flags, out, out_off + b0, out_len + b0,
+                                        consumed ? consumed + b0 : nullptr, final_code ? final_code + b0 : nullptr,
+                                        first_byte ? first_byte + b0 : nullptr, status + b0, nullptr, nullptr, 0, nullptr, 0);
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int r : rcs) if (r != ZPQ_OK) return r;
+    return ZPQ_OK;
+}
+
+extern "C" int zpq_encode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int nblocks, const uint8_t *in,
+                                       const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
+                                       uint32_t *out_len, int32_t *status)
+{
+    return multi_batch(ctxs, nctx, m, 0, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr, nullptr, status);
+}
+
+extern "C" int zpq_decode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int nblocks, const uint8_t *in,
+                                       const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
+                                       uint32_t *out_len, uint32_t *consumed, uint32_t *final_code, uint32_t *first_byte,
+                                       int32_t *status)
+{
+    return multi_batch(ctxs, nctx, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed, final_code, first_byte, status);
 }
 
 // ------------------------------------------------------------------ slab compaction

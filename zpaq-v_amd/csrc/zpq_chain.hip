@@ -1013,6 +1013,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const u32 c8n = (X.c8 << 1) | (u32)hyp;
                 if (bit == 5) prefetch_rows(hctx, c8n);
                 else { hn_spec = vm_hash(c8n - 256u); prefetch_rows(hn_spec, 1u); }
+                // (Asking one bit earlier still -- both outcomes of the last bit under this copy's outcome of the third,
+                //  four lines per nibble and table -- was measured: 320.7 vs 266.6 ms.  The memory system is loaded
+                //  enough that doubling the row reads costs more latency than the earlier request hides.)
             }
         };
         auto step = [&](auto kc, auto nbc) {
