@@ -211,6 +211,9 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
 // archive order and identical for any G (ctxs[0] also serves the sequential replay path).
 int archive_add(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive,
                 size_t fragment_bytes = 0);
+// archive_add over caller-owned bytes: no copy of the file contents on the way to the GPU (what the flat C surface uses)
+int archive_add_views(const std::vector<zpq_ctx *> &ctxs, int level, int nfiles, const char *const *names, const char *const *comments,
+                      const uint8_t *const *data, const uint64_t *lens, std::vector<uint8_t> *archive, size_t fragment_bytes = 0);
 // join_unnamed: a segment without a name is appended to the file before it (archives written with fragment_bytes).
 int archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_data, std::vector<ArchiveFile> *files,
                     bool join_unnamed = false);

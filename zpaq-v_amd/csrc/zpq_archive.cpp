@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "../../include/zpaq_frontend.hpp"
@@ -48,6 +49,53 @@ void host_sha1(const uint8_t *p, size_t n, uint8_t out[20])
     s.write_bytes(p, n);
     const std::vector<uint8_t> h = s.result();
     memcpy(out, h.data(), 20);
+}
+
+// Page-locked staging buffers, kept for the life of the process (pinning hundreds of MiB costs more than the
+// transfer it speeds up, so a buffer is pinned once and handed out again).
+struct PinnedPool {
+    struct Buf { void *p; size_t cap; bool busy; };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+    void *acquire(size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (Buf &b : bufs) if (!b.busy && b.cap >= n) { b.busy = true; return b.p; }
+        for (Buf &b : bufs) if (!b.busy) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; b.busy = true;      // regrow a free one
+            const size_t want = n + n / 8 + 4096;
+            if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; b.busy = false; return nullptr; }
+            b.cap = want; return b.p; }
+        Buf nb{nullptr, 0, true};
+        const size_t want = n + n / 8 + 4096;
+        if (hipHostMalloc(&nb.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        nb.cap = want;
+        bufs.push_back(nb);
+        return nb.p;
+    }
+    void release(void *p)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (Buf &b : bufs) if (b.p == p) b.busy = false;
+    }
+};
+PinnedPool &pinned_pool() { static PinnedPool *pool = new PinnedPool(); return *pool; }   // (never destroyed: HIP may be gone at exit)
+struct PinnedLease {
+    void *p = nullptr;
+    ~PinnedLease() { if (p) pinned_pool().release(p); }
+    bool get(size_t n) { p = pinned_pool().acquire(n ? n : 16); return p != nullptr; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// fn(i) for i in [0, n) on a few host threads (memcpy-bound work: 4 threads saturate a socket's copy bandwidth here)
+template <class F> void parallel_for(int n, uint64_t bytes, F fn)
+{
+    int T = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, bytes >> 23));
+    if (T > n) T = n > 0 ? n : 1;
+    if (T <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([=, &fn]() { for (int i = (int)((int64_t)n * t / T); i < (int)((int64_t)n * (t + 1) / T); i++) fn(i); });
+    for (std::thread &x : th) x.join();
 }
 
 struct VecWriter : Writer {
@@ -79,18 +127,37 @@ int archive_add(zpq_ctx *ctx, int level, const std::vector<ArchiveFile> &files, 
 
 // Several GPUs: block b -> context b mod G, one host thread per context, no collective; the
 // blocks are written out in their original order, so the archive does not depend on G.
+static void cut_pieces(std::vector<Piece> &pieces, const std::string &name, const std::string &comment, const uint8_t *p, size_t n, size_t fragment_bytes)
+{
+    if (fragment_bytes == 0 || n <= fragment_bytes) { pieces.push_back(Piece{name, comment, p, n}); return; }
+    for (size_t off = 0; off < n; off += fragment_bytes) {
+        const size_t k = std::min(fragment_bytes, n - off);
+        pieces.push_back(off == 0 ? Piece{name, comment, p, k} : Piece{"", "", p + off, k});
+    }
+}
+static int add_all(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<Piece> &pieces, std::vector<uint8_t> *archive);
+
 int archive_add(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<ArchiveFile> &files, std::vector<uint8_t> *archive,
                 size_t fragment_bytes)
 {
     if (!archive || level < 0 || level > 5 || ctxs.empty()) return ZPQ_E_ARG;
     std::vector<Piece> pieces;
-    for (const ArchiveFile &f : files) {
-        if (fragment_bytes == 0 || f.data.size() <= fragment_bytes) { pieces.push_back(Piece{f.name, f.comment, f.data.data(), f.data.size()}); continue; }
-        for (size_t off = 0; off < f.data.size(); off += fragment_bytes) {
-            const size_t k = std::min(fragment_bytes, f.data.size() - off);
-            pieces.push_back(off == 0 ? Piece{f.name, f.comment, f.data.data(), k} : Piece{"", "", f.data.data() + off, k});
-        }
-    }
+    for (const ArchiveFile &f : files) cut_pieces(pieces, f.name, f.comment, f.data.data(), f.data.size(), fragment_bytes);
+    return add_all(ctxs, level, pieces, archive);
+}
+
+// the same over caller-owned bytes (no copy of the file contents is made on the way to the GPU)
+int archive_add_views(const std::vector<zpq_ctx *> &ctxs, int level, int nfiles, const char *const *names, const char *const *comments,
+                      const uint8_t *const *data, const uint64_t *lens, std::vector<uint8_t> *archive, size_t fragment_bytes)
+{
+    if (!archive || level < 0 || level > 5 || ctxs.empty() || nfiles < 0) return ZPQ_E_ARG;
+    std::vector<Piece> pieces;
+    for (int i = 0; i < nfiles; i++) cut_pieces(pieces, names[i], comments[i], data[i], (size_t)lens[i], fragment_bytes);
+    return add_all(ctxs, level, pieces, archive);
+}
+
+static int add_all(const std::vector<zpq_ctx *> &ctxs, int level, const std::vector<Piece> &pieces, std::vector<uint8_t> *archive)
+{
     const size_t G = (level == 0 || pieces.size() < 2) ? 1 : std::min(ctxs.size(), pieces.size());
     if (G <= 1) return add_pieces(ctxs[0], level, pieces, archive, nullptr);
     std::vector<std::vector<Piece>> shard(G);
@@ -164,9 +231,23 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
         (rc = d_outoff.alloc(((size_t)n + 1) * 8)) || (rc = d_len.alloc((size_t)n * 4)) || (rc = d_st.alloc((size_t)n * 4)) ||
         (rc = d_sha.alloc((size_t)n * 20)))
         return rc;
-    for (int i = 0; i < n; i++)
-        if (files[i].n)
-            HK(hipMemcpyAsync(d_in.as<uint8_t>() + in_off[i], files[i].p, files[i].n, hipMemcpyHostToDevice, s));
+    {
+        // the files lie scattered in pageable memory: gather them into one pinned buffer on a few host threads, then
+        // one DMA (a hipMemcpyAsync per file is a staged, synchronous copy each: ~100 ms for 8192 files)
+        PinnedLease stage;
+        if (!stage.get(total)) return ZPQ_E_NOMEM;
+        uint8_t *h = stage.as<uint8_t>();
+        // in chunks of ~32 MiB: the DMA of one chunk runs while the next is being gathered
+        for (int i0 = 0; i0 < n;) {
+            int i1 = i0;
+            while (i1 < n && in_off[i1] - in_off[i0] < (32ull << 20)) i1++;
+            const uint64_t c0 = in_off[i0], cbytes = in_off[i1] - c0;
+            parallel_for(i1 - i0, cbytes, [&](int k) { const int i = i0 + k; if (files[i].n) memcpy(h + in_off[i], files[i].p, files[i].n); });
+            if (cbytes) HK(hipMemcpyAsync(d_in.as<uint8_t>() + c0, h + c0, cbytes, hipMemcpyHostToDevice, s));
+            i0 = i1;
+        }
+        HK(hipStreamSynchronize(s));                       // (the lease goes back to the pool here)
+    }
     HK(hipMemcpyAsync(d_inoff.p, in_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
     HK(hipMemcpyAsync(d_outoff.p, out_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
     HK(hipMemsetAsync(d_st.p, 0xff, (size_t)n * 4, s));
@@ -189,7 +270,9 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
         if (st[i] != ZPQ_OK) { lens[i] = 0; }
         pk_off[i + 1] = pk_off[i] + lens[i];
     }
-    std::vector<uint8_t> coded((size_t)pk_off[n]);
+    PinnedLease coded_lease;
+    if (!coded_lease.get((size_t)pk_off[n])) return ZPQ_E_NOMEM;
+    const uint8_t *const coded = coded_lease.as<uint8_t>();
     {
         DevMem d_pk, d_pkoff, d_len2;
         if ((rc = d_pk.alloc(pk_off[n] + 64)) || (rc = d_pkoff.alloc(((size_t)n + 1) * 8)) || (rc = d_len2.alloc((size_t)n * 4))) return rc;
@@ -198,7 +281,7 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
         if ((rc = zpq_gather_dev(ctx, n, d_out.as<uint8_t>(), d_outoff.as<uint64_t>(), d_len2.as<uint32_t>(), d_pk.as<uint8_t>(),
                                  d_pkoff.as<uint64_t>())) != ZPQ_OK)
             return rc;
-        if (!coded.empty()) HK(hipMemcpyAsync(coded.data(), d_pk.p, coded.size(), hipMemcpyDeviceToHost, s));
+        if (pk_off[n]) HK(hipMemcpyAsync(coded_lease.p, d_pk.p, (size_t)pk_off[n], hipMemcpyDeviceToHost, s));
         HK(hipStreamSynchronize(s));
     }
     if (!gpu_sha) for (int i = 0; i < n; i++) host_sha1(files[i].p, files[i].n, &sha[(size_t)i * 20]);
@@ -217,16 +300,36 @@ static int add_pieces(zpq_ctx *ctx, int level, const std::vector<Piece> &files, 
         big.resize(bl);
         redo[i] = std::move(big);
     }
+    // every block's bytes: [locator + header | segment header | payload | trailer | end of block].  All sizes are known
+    // now, so the archive is sized once and the blocks are written into place on a few host threads.
+    std::vector<uint8_t> head;                              // identical for every block of this level
+    { VecWriter hw(&head); framing::block_header(hw, hdr, hlen, cend, hbegin, hend); }
+    const size_t base = archive->size();
+    std::vector<size_t> at((size_t)n + 1, base);
     for (int i = 0; i < n; i++) {
-        framing::block_header(w, hdr, hlen, cend, hbegin, hend);
-        framing::segment_header(w, files[i].name, files[i].comment);
         auto it = redo.find(i);
-        if (it != redo.end()) w.write(it->second.data(), (int)it->second.size());
-        else w.write(coded.data() + pk_off[i], (int)lens[i]);
-        framing::segment_trailer(w, &sha[(size_t)i * 20]);
-        framing::block_end(w);
-        if (ends) ends->push_back(archive->size());
+        const size_t payload = it != redo.end() ? it->second.size() : lens[i];
+        at[i + 1] = at[i] + head.size() + (1 + files[i].name.size() + 1 + files[i].comment.size() + 1 + 1) + payload + (4 + 1 + 20) + 1;
     }
+    archive->resize(at[n]);
+    uint8_t *const A = archive->data();
+    parallel_for(n, at[n] - base, [&](int i) {
+        uint8_t *q = A + at[i];
+        memcpy(q, head.data(), head.size()); q += head.size();
+        *q++ = 1;                                                           // framing::segment_header
+        memcpy(q, files[i].name.data(), files[i].name.size()); q += files[i].name.size();
+        *q++ = 0;
+        memcpy(q, files[i].comment.data(), files[i].comment.size()); q += files[i].comment.size();
+        *q++ = 0; *q++ = 0;
+        auto it = redo.find(i);
+        if (it != redo.end()) { memcpy(q, it->second.data(), it->second.size()); q += it->second.size(); }
+        else { memcpy(q, coded + pk_off[i], lens[i]); q += lens[i]; }
+        *q++ = 0; *q++ = 0; *q++ = 0; *q++ = 0; *q++ = 253;                  // framing::segment_trailer
+        memcpy(q, &sha[(size_t)i * 20], 20); q += 20;
+        *q++ = 0xFF;                                                        // framing::block_end
+    });
+    if (ends) for (int i = 0; i < n; i++) ends->push_back(at[i + 1]);
+    (void)w;
     return ZPQ_OK;
 }
 
@@ -557,7 +660,9 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
                 uint64_t tot = 0, longest = 0;
                 for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) { tot += len[k]; longest = std::max<uint64_t>(longest, len[k]); }
                 const bool gpu_sha = gpu_sha1_pays(tot, longest);
-                std::vector<uint8_t> sha((size_t)m * 20, 0), slab;
+                std::vector<uint8_t> sha((size_t)m * 20, 0);
+                PinnedLease slab_lease;
+                const uint8_t *slab = nullptr;
                 if (gpu_sha) {
                     std::vector<uint64_t> rng((size_t)m * 2);      // begin[0..m) then end[0..m)
                     for (int k = 0; k < m; k++) { rng[(size_t)k] = out_off[k]; rng[(size_t)m + k] = out_off[k] + (st[k] == ZPQ_OK ? len[k] : 0); }
@@ -582,13 +687,14 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
                     if ((rc = zpq_gather_dev(ctx, m, d_out.as<uint8_t>(), d_outoff.as<uint64_t>(), d_plen.as<uint32_t>(), d_pk.as<uint8_t>(),
                                              d_pkoff.as<uint64_t>())) != ZPQ_OK)
                         return rc;
-                    slab.resize((size_t)pk_off[m]);
-                    if (!slab.empty()) HK(hipMemcpyAsync(slab.data(), d_pk.p, slab.size(), hipMemcpyDeviceToHost, s));
+                    if (!slab_lease.get((size_t)pk_off[m])) return ZPQ_E_NOMEM;
+                    slab = slab_lease.as<uint8_t>();
+                    if (pk_off[m]) HK(hipMemcpyAsync(slab_lease.p, d_pk.p, (size_t)pk_off[m], hipMemcpyDeviceToHost, s));
                     HK(hipStreamSynchronize(s));
-                    if (!gpu_sha) for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) host_sha1(slab.data() + pk_off[k], len[k], &sha[(size_t)k * 20]);
+                    if (!gpu_sha) for (int k = 0; k < m; k++) if (st[k] == ZPQ_OK) host_sha1(slab + pk_off[k], len[k], &sha[(size_t)k * 20]);
                 }
                 // ---- pass 3: trailer walk per block (Decoder.skip decoder.v:151-196, read_segment_end decompressor.v:590-635)
-                std::vector<int> again;
+                std::vector<int> again, fill;
                 for (int k = 0; k < m; k++) {
                     const size_t bi = (size_t)todo[k];
                     const BlockRec &b = blocks[bi];
@@ -616,8 +722,14 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
                     d.f.comment = b.comment;
                     d.f.sha1_ok = sha_ok;
                     d.f.size = first[k] == 0xFFFFFFFFu ? 0 : len[k];
-                    if (want_data && d.f.size) d.f.data.assign(slab.begin() + (ptrdiff_t)pk_off[k], slab.begin() + (ptrdiff_t)(pk_off[k] + len[k]));
+                    if (want_data && d.f.size) fill.push_back(k);
                 }
+                // the files' bytes out of the pinned slab, on a few host threads
+                if (!fill.empty())
+                    parallel_for((int)fill.size(), pk_off[m], [&](int j) {
+                        const int k = fill[(size_t)j];
+                        dec[(size_t)todo[k]].f.data.assign(slab + pk_off[k], slab + pk_off[k] + len[k]);
+                    });
                 todo.swap(again);
             }
         }
@@ -638,13 +750,7 @@ zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, c
                                           const uint8_t *const *data, const uint64_t *lens, uint64_t fragment_bytes, int *rc)
 {
     zpqf_archive *h = new zpqf_archive();
-    std::vector<zpaq::ArchiveFile> files((size_t)(nfiles > 0 ? nfiles : 0));
-    for (int i = 0; i < nfiles; i++) {
-        files[(size_t)i].name = names[i];
-        files[(size_t)i].comment = comments[i];
-        files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
-    }
-    const int r = zpaq::archive_add(ctx, level, files, &h->bytes, (size_t)fragment_bytes);
+    const int r = zpaq::archive_add_views(std::vector<zpq_ctx *>{ctx}, level, nfiles, names, comments, data, lens, &h->bytes, (size_t)fragment_bytes);
     if (rc) *rc = r;
     return h;
 }
@@ -653,13 +759,8 @@ zpqf_archive *zpqf_archive_add_multi(zpq_ctx *const *ctxs, int nctx, int level, 
                                      uint64_t fragment_bytes, int *rc)
 {
     zpqf_archive *h = new zpqf_archive();
-    std::vector<zpaq::ArchiveFile> files((size_t)(nfiles > 0 ? nfiles : 0));
-    for (int i = 0; i < nfiles; i++) {
-        files[(size_t)i].name = names[i];
-        files[(size_t)i].comment = comments[i];
-        files[(size_t)i].data.assign(data[i], data[i] + lens[i]);
-    }
-    const int r = zpaq::archive_add(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), level, files, &h->bytes, (size_t)fragment_bytes);
+    const int r = zpaq::archive_add_views(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), level, nfiles, names, comments, data, lens, &h->bytes,
+                                          (size_t)fragment_bytes);
     if (rc) *rc = r;
     return h;
 }
