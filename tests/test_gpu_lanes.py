@@ -9,6 +9,7 @@ import sys
 import pytest
 
 import oracle_lib as O
+import workload as W
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 from inputs import C4B, INPUTS  # noqa: E402
@@ -191,3 +192,29 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
     want = O.encode_blocks(C4B, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
     for i, w in zip(sample, want):
         assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+
+
+def test_four_blocks_per_wave_equals_one_block_per_wave(zpq, gpu_ctx, monkeypatch):
+    """Models with at most 16 components and the shipped hash-chain program ride four to a wave (k_rows: a block is a
+    16-lane row); the one-block-per-wave kernel stays for everything else.  Same model, same blocks, both kernels:
+    identical streams, equal to the oracle; a ragged batch so that rows of one wave end at different times, more blocks
+    than one workgroup holds, and a budget that makes rows reuse their slots."""
+    model = zpq.Model(header=C4B)
+    rnd = random.Random(16)
+    blocks = [bytes(W.make_block(7 * b + 1, rnd.choice([0, 1, 5, 64, 700, 2500, 6000]))) for b in range(41)]
+    want = [O.Codec(C4B).encode(b) for b in blocks]
+    rows, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert (status == 0).all() and rows == want
+    dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, rows, cap=8192)
+    assert (status == 0).all() and dec == blocks and (first == 0).all()
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 6 * model.state_bytes + 100)
+    try:
+        reuse, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_slots == 6 and (status == 0).all() and reuse == want
+    finally:
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+    monkeypatch.setenv("ZPQ_LANES_ROWS", "0")
+    one, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert (status == 0).all() and one == want
+    dec, status, *_ = gpu_ctx.decode_blocks(model, one, cap=8192)
+    assert (status == 0).all() and dec == blocks

@@ -1,0 +1,25 @@
+"""A spill to scratch in the bit loop is a 5x slowdown that no parity test sees (it happened twice while the
+round-2 kernels were written: a four-way register select turned into a stack array, and `cond ? vec4 : vec4` on
+ext-vector types lowered through memory).  The gfx950 code objects carry their resource usage in metadata, readable
+without a GPU: the kernels that code the shipped levels must use no scratch at all."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_specialised_kernels_use_no_scratch(zpq):
+    zpq.lib()                                                # built
+    from kernel_stats import kernel_table
+    t = kernel_table()
+    chain = {k: v for k, v in t.items() if "k_chain" in k}
+    assert len(chain) >= 20, sorted(t)
+    for name, r in chain.items():
+        runtime_loop = "Li0E" in name                         # NCH = 0: carries the ZPAQL interpreter (its byte array M needs a stack)
+        if not runtime_loop:
+            assert r["scratch"] == 0, (name, r)
+        assert r["vgpr"] <= 256, (name, r)                    # two waves of one workgroup may share a SIMD
+    for name, r in t.items():
+        if "k_lanes" in name and name.endswith("Lb1EEEv6DBatchNS_4LCfgE"):   # the hash-chain instantiation (no interpreter)
+            assert r["scratch"] == 0, (name, r)

@@ -32,5 +32,6 @@ which=sys.argv[1:] or ['C2','C4b','C3l3','C4a']
 if 'C2' in which: run('C2 level1 4096x64KiB', z.Model(level=1), 4096, 65536, z.FLAG_PP)
 if 'C3l3' in which: run('level3 2048x64KiB', z.Model(level=3), 2048, 65536, z.FLAG_PP)
 if 'C4b' in which: run('C4b all-9-types 4096x64KiB', z.Model(header=C4B), 4096, 65536, z.FLAG_PP, capmul=6)
+if 'C4b16k' in which: run('C4b all-9-types at capacity', z.Model(header=C4B), ctx.resident_capacity(z.Model(header=C4B)), 65536, z.FLAG_PP, capmul=6)
 if 'C4a' in which: run('C4a level5 1024x64KiB', z.Model(level=5), 1024, 65536, z.FLAG_PP)
 if 'L4' in which: run('level4 1536x64KiB', z.Model(level=4), 1536, 65536, z.FLAG_PP)
