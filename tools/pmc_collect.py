@@ -5,8 +5,23 @@ JSON files bench.py and DESIGN.md cite.  Usage on the GPU box, from /tmp:
   rocprofv3 --pmc SQ_... (two passes)
   python3 tools/pmc_collect.py OUT profiles/r01
 bench.py --steps 1 --warmup 0 launches every kernel twice (timed step + per-kernel timing step)."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, subprocess, sys
 src, dst = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_src_sha():                      # the same fingerprint bench.py computes: a profile is only cited for the source it was taken on
+    h = hashlib.sha256()
+    for f in ("zpq_chain.hip", "zpq_common.h", "zpq_vm.h"):
+        h.update(open(os.path.join(ROOT, "zpaq-v_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("ZPQ_COMMIT", "")
+    except Exception:
+        return os.environ.get("ZPQ_COMMIT", "")
 LAUNCHES = 2
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
@@ -26,6 +41,8 @@ for role in ("encode", "decode"):
             "hbm_bytes_per_launch_fetch_x2": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
 if pmc:
     pmc["_blocks_per_launch"] = 8192
+    pmc["_kernel_src_sha"] = kernel_src_sha()
+    pmc["_commit"] = commit()
     pmc["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 "
                     "--no-cpu-baseline` (level 2, 8192 x 64 KiB blocks per launch), aggregated by tools/pmc_collect.py. Unit: KB (x1024). "
                     "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE halves WIDE COALESCED 16 B/lane streams (128-B requests tallied at 64 B); "
@@ -35,5 +52,8 @@ if pmc:
     json.dump(pmc, open(dst + "_pmc.json", "w"), indent=1)
 sq = {role: {k: v for k, v in agg[role].items() if k.startswith("SQ_")} for role in ("encode", "decode")}
 if any(sq.values()):
+    sq["_kernel_src_sha"] = kernel_src_sha()
+    sq["_commit"] = commit()
+    sq["_note"] = "per launch, summed over the 1024 waves; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"
     json.dump(sq, open(dst + "_sq_counters.json", "w"), indent=1)
-print(json.dumps({"pmc": {k: v for k, v in pmc.items() if not k.startswith("_note")}, "sq_keys": sorted(sq["decode"])}, indent=1)[:1500])
+print(json.dumps({"pmc": {k: v for k, v in pmc.items() if not k.startswith("_note")}, "sq_keys": sorted(k for k in sq.get("decode", {}))}, indent=1)[:1500])
