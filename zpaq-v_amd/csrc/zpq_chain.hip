@@ -92,6 +92,12 @@ struct Cfg {
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
 __device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
+// (u64(range) * p16) >> 16 for p16 < 2^16 (encoder.v:60-61, decoder.v:86-87) without the 64-bit multiply:
+// range = hi * 2^16 + lo  =>  hi * p16 + ((lo * p16) >> 16), both products of 16-bit operands (two full-rate v_mul_u32_u24)
+__device__ __forceinline__ uint32_t mul_shr16(uint32_t range, uint32_t p16)
+{
+    return (uint32_t)__umul24(range >> 16, p16) + ((uint32_t)__umul24(range & 0xFFFFu, p16) >> 16);   // (__umul24 returns int)
+}
 __device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
 
 // value of lane (li-1) of the same 16-lane row; lane 0 of a row gets `self`
@@ -809,7 +815,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             i32 y = yk;
             if (is_last) {
                 const u32 p16 = (u32)sq * 2u + 1u;
-                const u32 mid = X.low + (u32)(((u64)(X.high - X.low) * p16) >> 16);
+                const u32 mid = X.low + mul_shr16(X.high - X.low, p16);
                 if (DEC) y = X.code <= mid ? 1 : 0;
                 X.high = y ? mid : X.high;
                 X.low = y ? X.low : mid + 1;
@@ -968,7 +974,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             i32 y = 0;
             if (is_last) {
                 const u32 p16 = (u32)sq * 2u + 1u;
-                const u32 mid = X.low + (u32)(((u64)(X.high - X.low) * p16) >> 16);
+                const u32 mid = X.low + mul_shr16(X.high - X.low, p16);
                 y = X.code <= mid ? 1 : 0;
                 X.high = y ? mid : X.high;
                 X.low = y ? X.low : mid + 1;
