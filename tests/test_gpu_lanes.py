@@ -69,12 +69,12 @@ def run_parity(zpq, ctx, header, blocks, cap=None):
     model = zpq.Model(header=header, offsets=offs)
     F = zpq.FLAG_PP | zpq.FLAG_LANES
     coded, status, _ = ctx.encode_blocks(model, blocks, cap=cap, flags=F)
-    assert ctx.last_kernel_name == "k_lanes<encode>"
+    assert ctx.last_kernel_name in ("k_lanes<encode>", "k_rows<encode>")     # (k_rows: n <= 16 and the hash-chain program)
     assert (status == 0).all(), status
     want = [O.Codec(header, offs).encode(b) for b in blocks]
     assert coded == want
     dec, status, consumed, _, first = ctx.decode_blocks(model, coded, cap=max(len(b) for b in blocks) + 16, flags=F)
-    assert ctx.last_kernel_name == "k_lanes<decode>"
+    assert ctx.last_kernel_name in ("k_lanes<decode>", "k_rows<decode>")
     assert (status == 0).all() and dec == blocks and (first == 0).all()
     assert [int(c) for c in consumed] == [len(c) for c in coded]
     return coded
@@ -91,7 +91,7 @@ def test_c4b_golden_streams(zpq, gpu_ctx):
         ks = [k for k in sorted(G["streams"]) if k.startswith("c4b/") and k.endswith(mode)]
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=zpq.FLAG_PP if mode == "pp" else 0)
-        assert gpu_ctx.last_kernel_name == "k_lanes<encode>" and (status == 0).all()
+        assert gpu_ctx.last_kernel_name == "k_rows<encode>" and (status == 0).all()
         for k, c in zip(ks, coded):
             assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k
         dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=8192, flags=zpq.FLAG_PP if mode == "pp" else 0)
@@ -180,7 +180,7 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
     d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
-    assert gpu_ctx.last_kernel_name == "k_lanes<encode>"
+    assert gpu_ctx.last_kernel_name == "k_rows<encode>"
     gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
                               in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
                               d_first.data_ptr(), d_dst.data_ptr())
@@ -213,8 +213,10 @@ def test_four_blocks_per_wave_equals_one_block_per_wave(zpq, gpu_ctx, monkeypatc
         assert gpu_ctx.last_slots == 6 and (status == 0).all() and reuse == want
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+    assert gpu_ctx.last_kernel_name == "k_rows<encode>"
     monkeypatch.setenv("ZPQ_LANES_ROWS", "0")
     one, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert gpu_ctx.last_kernel_name == "k_lanes<encode>"
     assert (status == 0).all() and one == want
     dec, status, *_ = gpu_ctx.decode_blocks(model, one, cap=8192)
     assert (status == 0).all() and dec == blocks

@@ -30,6 +30,7 @@ extern "C" int zpq_generic_blocks_per_cu(const DModel *M);
 extern "C" int zpq_lanes_supported(const DModel *M);
 extern "C" int zpq_lanes_blocks_per_cu(const DModel *M);
 extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode, int nslots, hipStream_t stream);
+extern "C" const char *zpq_lanes_kernel_name(const DModel *M, int decode);   // k_rows (four blocks per wave) or k_lanes
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
@@ -434,7 +435,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     } else if (want_lanes) {
         rc = zpq_launch_lanes(&B, &M, decode, nslots, c->stream);
         if (rc != ZPQ_OK) return rc;
-        c->last_name = decode ? "k_lanes<decode>" : "k_lanes<encode>";
+        c->last_name = zpq_lanes_kernel_name(&M, decode);
     } else {
         zpq_launch_generic(&B, &M, decode, grid, c->stream);
         c->last_name = decode ? "k_generic<decode>" : "k_generic<encode>";

@@ -1073,6 +1073,13 @@ extern "C" int zpq_lanes_blocks_per_cu(const DModel *M)
     return nb * zpql::WAVES * (rows ? zpql::RPW : 1);
 }
 
+extern "C" const char *zpq_lanes_kernel_name(const DModel *M, int decode)
+{
+    zpql::LCfg cfg;
+    const bool rows = lanes_cfg(M, &cfg) && rows_ok(cfg);
+    return rows ? (decode ? "k_rows<decode>" : "k_rows<encode>") : (decode ? "k_lanes<decode>" : "k_lanes<encode>");
+}
+
 extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode, int nslots, hipStream_t stream)
 {
     zpql::LCfg cfg;
