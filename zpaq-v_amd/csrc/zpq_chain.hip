@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // (Dense tables without a MIX2 only: with the line store the second probe doubles tag loads and selects, and the
     //  MIX2 levels have eight tables to fetch twice -- measured slower there: level 5 505 vs 466 ms.)
     constexpr bool TWO = DEC && !SPEC && !HYP && NCH > 0 && !SP && !MIXT;
+    // (Requesting only the LIKELIER outcome early -- as soon as the last bit's probability is known, asking again after
+    //  a wrong guess -- was measured as well: level 3 375 -> 472 ms, level 5 467 -> 557 ms.  Every speculative row read
+    //  these decoders add costs more in memory latency under load than it hides; they request after the bit is known.)
     const int hyp = HYP ? ((li >> 2) & 1) : 0;           // the outcome this lane assumes
     const int lc = HYP ? (li & 3) : li;                  // the component this lane works for
     const int ctype = (lc < n) ? M.comp[lc].type : 0;
