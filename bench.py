@@ -302,119 +302,141 @@ def main():
         }
 
     if rank == 0 and world == 1 and not a.no_secondary:
-        # ---- per class: the headline workload, one block class at a time (each class's blocks of the headline
-        #      batch repeated to the same launch size, so residency and launch shape are the headline's)
-        per_class = {}
-        names = ["zeros", "uniform", "markov_text", "periodic"]
-        for cls in range(4):
-            idx = torch.arange(cls, nb, 4, device=dev)
-            reps = (nb + idx.numel() - 1) // idx.numel()
-            sel = idx.repeat(reps)[:nb]
-            d_cls = d_in.view(nb, size).index_select(0, sel).reshape(-1).contiguous()
-            torch.cuda.synchronize()
-            rb.enc_ms.clear(); rb.dec_ms.clear()
-            rb.step(model, d_cls, flags)
-            rb.step(model, d_cls, flags, record=True)
-            okc = rb.ok(d_cls)
-            e, d = rb.enc_ms[-1], rb.dec_ms[-1]
-            per_class[names[cls]] = {"comp_MBps": round(nb * size / e / 1e3, 1), "decomp_MBps": round(nb * size / d / 1e3, 1),
-                                     "roundtrip_MBps": round(nb * size / (e + d) / 1e3, 1),
-                                     "ratio": round(rb.coded_bytes() / (nb * size), 4), "roundtrip_bit_exact": okc}
-            del d_cls
-        res["per_class"] = per_class
+        # Every extra below is optional: a failure there (say, no room for the pinned buffers) is recorded in the line,
+        # it never costs the headline.
+        extras_failed = {}
         cap = rb.cap
-        del rb
-        torch.cuda.empty_cache()
 
-        # ---- PCIe-inclusive: the same batch through the host-pointer entry points (what a V front end holding
-        #      host buffers calls): H2D + kernel + D2H inside each call.  Buffers come from zpq_host_alloc (pinned);
-        #      the decoder is handed the coded streams packed back to back, as an archive holds them.
-        L = z.lib()
+        def _per_class():
+            # ---- per class: the headline workload, one block class at a time (each class's blocks of the headline
+            #      batch repeated to the same launch size, so residency and launch shape are the headline's)
+            per_class = {}
+            names = ["zeros", "uniform", "markov_text", "periodic"]
+            for cls in range(4):
+                idx = torch.arange(cls, nb, 4, device=dev)
+                reps = (nb + idx.numel() - 1) // idx.numel()
+                sel = idx.repeat(reps)[:nb]
+                d_cls = d_in.view(nb, size).index_select(0, sel).reshape(-1).contiguous()
+                torch.cuda.synchronize()
+                rb.enc_ms.clear(); rb.dec_ms.clear()
+                rb.step(model, d_cls, flags)
+                rb.step(model, d_cls, flags, record=True)
+                okc = rb.ok(d_cls)
+                e, d = rb.enc_ms[-1], rb.dec_ms[-1]
+                per_class[names[cls]] = {"comp_MBps": round(nb * size / e / 1e3, 1), "decomp_MBps": round(nb * size / d / 1e3, 1),
+                                         "roundtrip_MBps": round(nb * size / (e + d) / 1e3, 1),
+                                         "ratio": round(rb.coded_bytes() / (nb * size), 4), "roundtrip_bit_exact": okc}
+                del d_cls
+            res["per_class"] = per_class
 
-        def incl_pcie(nblk, arr2d, what):
-            nbytes = nblk * size
-            in_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(size)
-            out_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(cap)
-            p_src, p_out, p_dec = z.PinnedArray(nbytes), z.PinnedArray(nblk * cap), z.PinnedArray(nbytes)
-            p_src.array[:] = arr2d.reshape(-1)
-            olen = np.zeros(nblk, dtype=np.uint32); st = np.zeros(nblk, dtype=np.int32)
-            dlen = np.zeros(nblk, dtype=np.uint32); dst = np.zeros(nblk, dtype=np.int32)
-            r = {}
-            for rep in range(2):
-                t0 = time.time()
-                rc1 = L.zpq_encode_blocks(ctx.h, model.h, nblk, p_src.array.ctypes.data, in_off.ctypes.data, flags,
-                                          p_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
-                t1 = time.time()
-                # pack the coded streams (outside the timed calls: an archive already holds them like this)
-                c_off = np.zeros(nblk + 1, dtype=np.uint64)
-                c_off[1:] = np.cumsum(olen.astype(np.uint64))
-                if rep == 0:
-                    p_cod = z.PinnedArray(int(c_off[-1]) + 16)
-                    for i in range(nblk):
-                        p_cod.array[int(c_off[i]):int(c_off[i + 1])] = p_out.array[i * cap:i * cap + int(olen[i])]
-                t2 = time.time()
-                rc2 = L.zpq_decode_blocks(ctx.h, model.h, nblk, p_cod.array.ctypes.data, c_off.ctypes.data, flags,
-                                          p_dec.array.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, None, None, None,
-                                          dst.ctypes.data)
-                t3 = time.time()
-                tt = (t1 - t0) + (t3 - t2)
-                r = {"value": round(nbytes / tt / 1e6, 1), "unit": "MB/s", "blocks": nblk, "rounds": -(-nblk // ctx.last_slots),
-                     "comp_MBps": round(nbytes / (t1 - t0) / 1e6, 1), "decomp_MBps": round(nbytes / (t3 - t2) / 1e6, 1),
-                     "ok": bool(rc1 == 0 and rc2 == 0 and (st == 0).all() and (dst == 0).all()
-                                and np.array_equal(p_dec.array, p_src.array)),
-                     "what": what}
-            for pa in (p_src, p_out, p_dec, p_cod):
-                pa.free()
-            return r
 
-        pc = incl_pcie(nb, host, "zpq_encode_blocks + zpq_decode_blocks on pinned host buffers (zpq_host_alloc), the headline batch in "
-                                 "one round: upload, kernel and download in series; second of two calls")
-        res["value_incl_pcie"] = pc["value"]
-        res["incl_pcie"] = pc
-        res["incl_pcie"]["fraction_of_device_resident"] = round(pc["value"] / res["value"], 4)
-        host2 = np.concatenate([host, host, host, host])
-        ps = incl_pcie(4 * nb, host2, "the same calls on a batch of four times the resident capacity: four rounds, the upload of round "
-                                      "r+1 and the download of round r-1 overlap the coding of round r (host_pipeline)")
-        res["incl_pcie_streamed"] = ps
-        res["incl_pcie_streamed"]["fraction_of_device_resident"] = round(ps["value"] / res["value"], 4)
-        del host2
+        def _incl_pcie():
+            # ---- PCIe-inclusive: the same batch through the host-pointer entry points (what a V front end holding
+            #      host buffers calls): H2D + kernel + D2H inside each call.  Buffers come from zpq_host_alloc (pinned);
+            #      the decoder is handed the coded streams packed back to back, as an archive holds them.
+            L = z.lib()
 
-        # ---- secondary configs, device-resident like the headline
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        from inputs import C4B
-        secondary = {}
+            def incl_pcie(nblk, arr2d, what):
+                nbytes = nblk * size
+                in_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(size)
+                out_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(cap)
+                p_src, p_out, p_dec = z.PinnedArray(nbytes), z.PinnedArray(nblk * cap), z.PinnedArray(nbytes)
+                p_src.array[:] = arr2d.reshape(-1)
+                olen = np.zeros(nblk, dtype=np.uint32); st = np.zeros(nblk, dtype=np.int32)
+                dlen = np.zeros(nblk, dtype=np.uint32); dst = np.zeros(nblk, dtype=np.int32)
+                r = {}
+                for rep in range(2):
+                    t0 = time.time()
+                    rc1 = L.zpq_encode_blocks(ctx.h, model.h, nblk, p_src.array.ctypes.data, in_off.ctypes.data, flags,
+                                              p_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
+                    t1 = time.time()
+                    # pack the coded streams (outside the timed calls: an archive already holds them like this)
+                    c_off = np.zeros(nblk + 1, dtype=np.uint64)
+                    c_off[1:] = np.cumsum(olen.astype(np.uint64))
+                    if rep == 0:
+                        p_cod = z.PinnedArray(int(c_off[-1]) + 16)
+                        for i in range(nblk):
+                            p_cod.array[int(c_off[i]):int(c_off[i + 1])] = p_out.array[i * cap:i * cap + int(olen[i])]
+                    t2 = time.time()
+                    rc2 = L.zpq_decode_blocks(ctx.h, model.h, nblk, p_cod.array.ctypes.data, c_off.ctypes.data, flags,
+                                              p_dec.array.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, None, None, None,
+                                              dst.ctypes.data)
+                    t3 = time.time()
+                    tt = (t1 - t0) + (t3 - t2)
+                    r = {"value": round(nbytes / tt / 1e6, 1), "unit": "MB/s", "blocks": nblk, "rounds": -(-nblk // ctx.last_slots),
+                         "comp_MBps": round(nbytes / (t1 - t0) / 1e6, 1), "decomp_MBps": round(nbytes / (t3 - t2) / 1e6, 1),
+                         "ok": bool(rc1 == 0 and rc2 == 0 and (st == 0).all() and (dst == 0).all()
+                                    and np.array_equal(p_dec.array, p_src.array)),
+                         "what": what}
+                for pa in (p_src, p_out, p_dec, p_cod):
+                    pa.free()
+                return r
 
-        def run_cfg(key, what, mdl, want_nb, A_minus_r, capmul, names_):
-            cap_res = ctx.resident_capacity(mdl, flags)
-            n = min(want_nb, cap_res) if want_nb else cap_res
-            arr = host[:n] if n <= nb else np.concatenate([host] * ((n + nb - 1) // nb))[:n]
-            d = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1)).to(dev)
-            b = ResidentBatch(z, ctx, torch, dev, n, size, capmul)
-            b.step(mdl, d, flags, record=True)
-            b.step(mdl, d, flags, record=True)
-            e, dd = min(b.enc_ms), min(b.dec_ms)
-            r = b.coded_bytes() / (n * size)
-            secondary[key] = {
-                "workload": what, "blocks": n, "resident_blocks": ctx.last_slots, "resident_capacity": cap_res,
-                "comp_MBps": round(n * size / e / 1e3, 1), "decomp_MBps": round(n * size / dd / 1e3, 1),
-                "roundtrip_MBps": round(n * size / (e + dd) / 1e3, 1), "ratio": round(r, 4),
-                "kernel_ms": {b.enc_name: round(e, 2), b.dec_name: round(dd, 2)},
-                "roundtrip_bit_exact": b.ok(d),
-                "roofline": roofline_of(A_minus_r, r, n, size, e, dd, (b.enc_name, b.dec_name))}
-            del b, d
-            torch.cuda.empty_cache()
+            pc = incl_pcie(nb, host, "zpq_encode_blocks + zpq_decode_blocks on pinned host buffers (zpq_host_alloc), the headline batch in "
+                                     "one round: upload, kernel and download in series; second of two calls")
+            res["value_incl_pcie"] = pc["value"]
+            res["incl_pcie"] = pc
+            res["incl_pcie"]["fraction_of_device_resident"] = round(pc["value"] / res["value"], 4)
+            host2 = np.concatenate([host, host, host, host])
+            ps = incl_pcie(4 * nb, host2, "the same calls on a batch of four times the resident capacity: four rounds, the upload of round "
+                                          "r+1 and the download of round r-1 overlap the coding of round r (host_pipeline)")
+            res["incl_pcie_streamed"] = ps
+            res["incl_pcie_streamed"]["fraction_of_device_resident"] = round(ps["value"] / res["value"], 4)
+            del host2
 
-        run_cfg("C2_level1", "level 1 (%s, levels.v:53-92), 4096 x 64 KiB" % LEVEL_NAMES[1], z.Model(level=1), 4096,
-                ALG_BYTES_PER_INPUT_BYTE_L[1], 1.125, None)
-        run_cfg("level3", "level 3 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[3], z.Model(level=3), 0,
-                ALG_BYTES_PER_INPUT_BYTE_L[3], 1.125, None)
-        run_cfg("level4", "level 4 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[4], z.Model(level=4), 0,
-                ALG_BYTES_PER_INPUT_BYTE_L[4], 1.125, None)
-        run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
-                z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None)
-        run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 64 KiB blocks at resident "
-                                      "capacity (four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
-        res["secondary"] = secondary
+
+        def _secondary():
+            # ---- secondary configs, device-resident like the headline
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            from inputs import C4B
+            secondary = {}
+
+            def run_cfg(key, what, mdl, want_nb, A_minus_r, capmul, names_):
+                cap_res = ctx.resident_capacity(mdl, flags)
+                n = min(want_nb, cap_res) if want_nb else cap_res
+                arr = host[:n] if n <= nb else np.concatenate([host] * ((n + nb - 1) // nb))[:n]
+                d = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1)).to(dev)
+                b = ResidentBatch(z, ctx, torch, dev, n, size, capmul)
+                b.step(mdl, d, flags, record=True)
+                b.step(mdl, d, flags, record=True)
+                e, dd = min(b.enc_ms), min(b.dec_ms)
+                r = b.coded_bytes() / (n * size)
+                secondary[key] = {
+                    "workload": what, "blocks": n, "resident_blocks": ctx.last_slots, "resident_capacity": cap_res,
+                    "comp_MBps": round(n * size / e / 1e3, 1), "decomp_MBps": round(n * size / dd / 1e3, 1),
+                    "roundtrip_MBps": round(n * size / (e + dd) / 1e3, 1), "ratio": round(r, 4),
+                    "kernel_ms": {b.enc_name: round(e, 2), b.dec_name: round(dd, 2)},
+                    "roundtrip_bit_exact": b.ok(d),
+                    "roofline": roofline_of(A_minus_r, r, n, size, e, dd, (b.enc_name, b.dec_name))}
+                del b, d
+                torch.cuda.empty_cache()
+
+            run_cfg("C2_level1", "level 1 (%s, levels.v:53-92), 4096 x 64 KiB" % LEVEL_NAMES[1], z.Model(level=1), 4096,
+                    ALG_BYTES_PER_INPUT_BYTE_L[1], 1.125, None)
+            run_cfg("level3", "level 3 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[3], z.Model(level=3), 0,
+                    ALG_BYTES_PER_INPUT_BYTE_L[3], 1.125, None)
+            run_cfg("level4", "level 4 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[4], z.Model(level=4), 0,
+                    ALG_BYTES_PER_INPUT_BYTE_L[4], 1.125, None)
+            run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
+                    z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None)
+            run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 64 KiB blocks at resident "
+                                          "capacity (four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
+            res["secondary"] = secondary
+
+        for _name, _fn in (("per_class", _per_class), ("incl_pcie", _incl_pcie), ("secondary", _secondary)):
+            try:
+                _fn()
+            except Exception as e:                                   # noqa: BLE001
+                extras_failed[_name] = repr(e)[:300]
+            if _name == "per_class":                                 # the headline's device buffers are not needed any more
+                rb = None
+                torch.cuda.empty_cache()
+                try:
+                    torch.cuda.empty_cache()
+                except Exception:                                    # noqa: BLE001
+                    pass
+        if extras_failed:
+            res["extras_failed"] = extras_failed
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
