@@ -642,7 +642,14 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
     u8 *ht = slot + C.ht_off;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
     const bool hashed = type == ZT_ICM || type == ZT_ISSE;
-    auto tab_of = [&](int ci) -> u32 * { return reinterpret_cast<u32 *>(slot + M.comp[ci].cm_off); };   // this row's block, component ci
+    // Model constants of component ci: lane ci of ROW 0 holds them in registers (every row carries the same model), so
+    // v_readlane hands them out as scalars -- no scalar memory load of M.comp[ci] per bit.
+    const u32 cmo_lo = (u32)C.cm_off, cmo_hi = (u32)(C.cm_off >> 32);
+    auto cst = [&](i32 reg, int ci) -> i32 { return __builtin_amdgcn_readlane(reg, ci); };
+    auto tab_of = [&](int ci) -> u32 * {                          // this row's block, component ci
+        const u64 off = (u64)(u32)cst((i32)cmo_lo, ci) | ((u64)(u32)cst((i32)cmo_hi, ci) << 32);
+        return reinterpret_cast<u32 *>(slot + off);
+    };
     auto rowget = [&](i32 v, int x) -> i32 { return __builtin_amdgcn_ds_bpermute((rb + (x & (RL - 1))) << 2, v); };  // lane x of my row
 
     auto squash = [&](i32 d) -> i32 { return s_squash[min(max(wadd(d, 2047), 0), 4093)]; };
@@ -769,28 +776,28 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                 i32 pj0 = -1, pj1 = -1;
                 if (cfg.mix_ci[0] >= 0) {
                     const int ci = cfg.mix_ci[0];
-                    const i32 j = M.comp[ci].b, m = M.comp[ci].limit;
+                    const i32 j = cst(cb, ci), m = cst(climit, ci);
                     const i32 idx = wmul(rowget((i32)cxt, ci), m);
                     const i32 l = (li - idx) & (RL - 1);
                     if (l < m && (j + l) < n) { pj0 = j + l; pa0 = tab_of(ci) + (idx + l); pw0 = *pa0; }
                 }
                 if (cfg.mix_ci[1] >= 0) {
                     const int ci = cfg.mix_ci[1];
-                    const i32 j = M.comp[ci].b, m = M.comp[ci].limit;
+                    const i32 j = cst(cb, ci), m = cst(climit, ci);
                     const i32 idx = wmul(rowget((i32)cxt, ci), m);
                     const i32 l = (li - idx) & (RL - 1);
                     if (l < m && (j + l) < n) { pj1 = j + l; pa1 = tab_of(ci) + (idx + l); pw1 = *pa1; }
                 }
                 if (cfg.sse_ci[0] >= 0) {
                     const int ci = cfg.sse_ci[0];
-                    const i32 base = rowget((i32)cxt, ci), len = (i32)M.comp[ci].cm_len;
+                    const i32 base = rowget((i32)cxt, ci), len = cst((i32)cm_len, ci);
                     const i32 ia = wadd(base, li), ib = wadd(base, li + RL);
                     if (ia >= 0 && ia < len) srA0 = tab_of(ci)[ia];
                     if (ib >= 0 && ib < len) srB0 = tab_of(ci)[ib];
                 }
                 if (cfg.sse_ci[1] >= 0) {
                     const int ci = cfg.sse_ci[1];
-                    const i32 base = rowget((i32)cxt, ci), len = (i32)M.comp[ci].cm_len;
+                    const i32 base = rowget((i32)cxt, ci), len = cst((i32)cm_len, ci);
                     const i32 ia = wadd(base, li), ib = wadd(base, li + RL);
                     if (ia >= 0 && ia < len) srA1 = tab_of(ci)[ia];
                     if (ib >= 0 && ib < len) srB1 = tab_of(ci)[ib];
@@ -811,7 +818,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                 i32 pin0 = 0, pin1 = 0;
                 for (u64 dm = cfg.depmask; dm != 0; dm &= dm - 1) {
                     const int ci = __builtin_ctzll(dm);
-                    const int ty = M.comp[ci].type;
+                    const int ty = cst(type, ci);
                     auto inp = [&](int x) -> i32 { return x < ci ? rowget(pown, x) : rowget(pprev, x); };   // x uniform, < n
                     if (ty == ZT_MIX) {
                         const i32 merged = li < ci ? pown : pprev;
@@ -825,7 +832,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                             pin1 = pj1 >= 0 ? t : 0;
                             part = wmul((i32)pw1 >> 8, pin1);
                         } else {
-                            const i32 j = M.comp[ci].b, m = M.comp[ci].limit;
+                            const i32 j = cst(cb, ci), m = cst(climit, ci);
                             const i32 idx = wmul(rowget((i32)cxt, ci), m);
                             const i32 l = (li - idx) & (RL - 1);
                             const bool mine = l < m && (j + l) < n;
@@ -835,17 +842,17 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                         const i32 sum = row_sum_all(part, rb);
                         if (li == ci) pown = clamp2k(sum >> 8);
                     } else if (ty == ZT_AVG) {
-                        const i32 xa = M.comp[ci].a, xb = M.comp[ci].b;
+                        const i32 xa = cst(ca, ci), xb = cst(cb, ci);
                         const bool ok = xa < n && xb < n;
                         const i32 ia = ok ? inp(xa) : 0, ib = ok ? inp(xb) : 0;
                         if (li == ci) pown = ok ? (wadd(wmul(ia, cc), wmul(ib, 256 - cc)) >> 8) : 0;
                     } else if (ty == ZT_MIX2) {
-                        const i32 xj = M.comp[ci].j, xk = M.comp[ci].k;
+                        const i32 xj = cst(cj, ci), xk = cst(ck, ci);
                         const bool ok = xj < n && xk < n;
                         const i32 ij = ok ? inp(xj) : 0, ik = ok ? inp(xk) : 0;
                         if (li == ci) { const i32 w = (i32)v0; pown = ok ? clamp2k(wadd(wmul(w, ij), wmul(65536 - w, ik)) >> 16) : 0; }
                     } else if (ty == ZT_ISSE) {
-                        const i32 xb = M.comp[ci].b;
+                        const i32 xb = cst(cb, ci);
                         const bool ok = xb < n;
                         const i32 ib = ok ? inp(xb) : 0;
                         if (li == ci) {
@@ -853,7 +860,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                             pown = ok ? clamp2k(wadd(wmul(w0, ib), wmul(w1, 64)) >> 16) : clamp2k(w1 >> 10);
                         }
                     } else {                                       // SSE
-                        const i32 xb = M.comp[ci].b;
+                        const i32 xb = cst(cb, ci);
                         i32 pq = 992;
                         if (xb < n) pq = wadd(inp(xb), 992);
                         pq = min(max(pq, 0), 1983);
@@ -967,7 +974,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                         const i32 fin = rowget(pown, pj1);
                         if (pj1 >= 0) *pa1 = (u32)clamp512k(wadd((i32)pw1, wadd(wmul(err, fin), 1 << 12) >> 13));
                     } else {
-                        const i32 jj = M.comp[ci].b, m = M.comp[ci].limit;
+                        const i32 jj = cst(cb, ci), m = cst(climit, ci);
                         const i32 idx = wmul(rowget((i32)cxt, ci), m);
                         const i32 l = (li - idx) & (RL - 1);
                         const i32 fin = rowget(pown, jj + l);
