@@ -77,7 +77,7 @@ int zpq_ctx_device(const zpq_ctx *); /* HIP device index the ctx was created on 
 int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
 /* Largest block (bytes) the caller will submit to the chain kernel: sizes the compact line store
  * that stands in for every hash table larger than it (a block of N bytes touches at most 2(N+2)
- * lines per table, predictor.v:495-532,558-560; the store holds 1.25x that).  Default 65536: level 1's
+ * lines per table, predictor.v:495-532,558-560; the store holds 1.12x that).  Default 65536: level 1's
  * ISSE and all tables of levels 3-5 use the store, level 2's 4 MiB tables stay dense.  A bigger block gets
  * ZPQ_E_TOOBIG in status[] instead of wrong output. */
 int zpq_ctx_set_max_block_bytes(zpq_ctx *, uint64_t bytes);

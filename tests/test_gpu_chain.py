@@ -361,7 +361,7 @@ def test_mix2_levels_ragged_batch_with_slot_reuse(zpq, gpu_ctx, level):
     rnd = random.Random(90 + level)
     blocks = [bytes(W.make_block(3 * b + level, rnd.choice([0, 1, 2, 15, 16, 17, 300, 1500, 4000]))) for b in range(14)]
     want = O.encode_blocks(model.header, blocks, nthreads=4)
-    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 300 << 20)      # 3-4 slots of the compact layout (about 64 / 86 MiB)
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 300 << 20)      # 3-5 slots of the compact layout (about 58 / 77 MiB)
     try:
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
         assert gpu_ctx.last_kernel_name == "k_chain<encode>" and 2 <= gpu_ctx.last_slots <= 5

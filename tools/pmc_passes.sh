@@ -10,7 +10,7 @@ P3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VM
 i=0
 for p in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $p -d $out/p$i -o p$i --output-format csv -- python3 tools/prof_run.py "$@" > $out/p$i.log 2>&1
+  rocprofv3 --pmc $p -d $out/p$i -o p$i --output-format csv -- python3 ${PROF_TARGET:-tools/prof_run.py} "$@" > $out/p$i.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, os, json
@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_chain" not in k and "k_lanes" not in k: continue
+        if "k_chain" not in k and "k_lanes" not in k and "k_rows" not in k: continue
         role = ("decode" if ("<true" in k or "ILb1" in k) else "encode")
         agg[role][r["Counter_Name"]] += float(r["Counter_Value"])
 json.dump(agg, open(os.path.join(sys.argv[1], "sq.json"), "w"), indent=1)

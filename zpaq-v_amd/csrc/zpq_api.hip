@@ -92,7 +92,7 @@ struct zpq_ctx {
     uint8_t *d_ns = nullptr;
     std::map<uint64_t, DevModel> models;   // key = model id << 32 | compact-store capacity (0 = dense layout)
     uint32_t sparse_cap = 0;               // line-store capacity (lines) for the largest block the caller submits
-    uint32_t sparse_pct = 125;             // capacity = this percentage of the lines a largest block can touch
+    uint32_t sparse_pct = 112;             // capacity = this percentage of the lines a largest block can touch (125: measured 4-7 % slower at levels 4-5, fewer blocks fit)
     DevBuf slots;
     uint64_t budget = 0;
     int last_slots = 0;
@@ -253,7 +253,7 @@ extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
     if (!c) return ZPQ_E_ARG;
     // A block of N bytes (+ PP byte) probes each hash table 2(N+1) times (predictor.v:558-560: once per nibble),
     // so it touches at most that many 64-byte lines.  The store holds sparse_pct % of that bound: probing is
-    // linear over 4-slot groups, a worst-case block (every probe a new line) ends at 80 % load.
+    // linear over 4-slot groups, a worst-case block (every probe a new line) ends at 89 % load.
     const uint64_t probes = 2 * (bytes + 2);
     uint64_t cap = (probes * c->sparse_pct + 99) / 100 + 16;
     cap = (cap + 3) & ~3ull;

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // the compiler wait for them at once and defeat the prefetch); only the store is masked
     const u32 ht_mask = hashed ? ((C.ht_len - 16u) & cfg.dbg_ht_and) : 0u;
     // compact line store: u32 tags[cap] (dense line index + 1, 0 = free) + 64-byte lines[cap] instead of the dense
-    // table.  cap is a multiple of 4, about 1.25x the lines the largest block can touch (zpq_ctx_set_max_block_bytes).
+    // table.  cap is a multiple of 4, about 1.12x the lines the largest block can touch (zpq_ctx_set_max_block_bytes).
     constexpr bool SPARSE = SP;
     const u32 sp_cap = (SPARSE && hashed) ? C.sp_cap : 0u;
     const u32 sp_groups = sp_cap >> 2;
