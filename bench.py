@@ -373,7 +373,7 @@ def main():
                 return r
 
             pc = incl_pcie(nb, host, "zpq_encode_blocks + zpq_decode_blocks on pinned host buffers (zpq_host_alloc), the headline batch in "
-                                     "one round: upload, kernel and download in series; second of two calls")
+                                     "one round: striped upload / download beside the kernel (host_pipeline, HIO kernels); second of two calls")
             res["value_incl_pcie"] = pc["value"]
             res["incl_pcie"] = pc
             res["incl_pcie"]["fraction_of_device_resident"] = round(pc["value"] / res["value"], 4)

@@ -108,3 +108,37 @@ def test_decode_multi_matches_single(zpq, gpu_ctx):
         assert got == blocks and [int(c) for c in cons] == [len(c) for c in coded]
     finally:
         other.close()
+
+
+def test_striped_upload_equals_plain_upload(zpq, gpu_ctx, monkeypatch):
+    """A single round of equally long blocks from pinned memory is uploaded in two stripes: the first 8 KiB of every block,
+    then -- beside the running encoder -- the rest, with an in-kernel gate on a pinned flag.  Same streams as the plain
+    upload and as the oracle; block contents differ in BOTH stripes, so a lane that read past the gate too early, or
+    stale bytes, would show."""
+    model = zpq.Model(level=2)
+    nb, size = 160, 40960
+    blocks = [bytes(W.make_block(b, size)) for b in range(nb)]
+    caps = [size + size // 8 + 1024] * nb
+    striped = _encode_raw(zpq, [gpu_ctx], model, blocks, caps, pinned=True)
+    monkeypatch.setenv("ZPQ_NO_STRIPE", "1")
+    plain = _encode_raw(zpq, [gpu_ctx], model, blocks, caps, pinned=True)
+    assert striped == plain
+    sample = [0, 1, 2, 3, 77, 158, 159]
+    assert [striped[i] for i in sample] == O.encode_blocks(model.header, [blocks[i] for i in sample], nthreads=4)
+    dec, status, *_ = gpu_ctx.decode_blocks(model, striped, cap=size)
+    assert (status == 0).all() and dec == blocks
+    # and the mirror image: the decoder's output leaves in two stripes, the first one beside the running kernel once
+    # every block has reported its first 3/4 stored (release at system scope + a counter in pinned memory)
+    monkeypatch.delenv("ZPQ_NO_STRIPE")
+    L = zpq.lib()
+    in_off, out_off = _layout(striped, [size] * nb)
+    pin_in, pin_out = zpq.PinnedArray(int(in_off[-1]) + 16), zpq.PinnedArray(nb * size)
+    pin_in.array[:int(in_off[-1])] = np.frombuffer(b"".join(striped), dtype=np.uint8)
+    for rep in range(2):
+        pin_out.array[:] = 0xEE
+        olen = np.zeros(nb, dtype=np.uint32); st = np.full(nb, -99, dtype=np.int32); first = np.zeros(nb, dtype=np.uint32)
+        rc = L.zpq_decode_blocks(gpu_ctx.h, model.h, nb, pin_in.array.ctypes.data, in_off.ctypes.data, zpq.FLAG_PP,
+                                 pin_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, None, None, first.ctypes.data,
+                                 st.ctypes.data)
+        assert rc == 0 and (st == 0).all() and (olen == size).all() and (first == 0).all()
+        assert pin_out.array.tobytes() == b"".join(blocks)

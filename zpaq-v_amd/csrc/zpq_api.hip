@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <map>
 #include <mutex>
@@ -37,6 +38,7 @@ extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
                                 hipStream_t stream);
 extern "C" const char *zpq_chain_kernel_name(const DModel *M, int decode);
+extern "C" int zpq_chain_has_hio(const DModel *M);   // kernels that take part in striped host transfers exist for this model
 extern "C" int zpq_launch_sha1(const uint8_t *in, const uint64_t *beg, const uint64_t *end, int n, uint8_t *out20, hipStream_t stream);
 
 #define HIPCK(x)                                                              \
@@ -123,6 +125,7 @@ struct zpq_ctx {
         }
     } pipe[2];
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    uint32_t *h_gate = nullptr;            // pinned, device-visible: "the rest of the striped upload has arrived"
     std::mutex mu;
 };
 
@@ -172,6 +175,8 @@ static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
     HIPCK(hipEventCreate(&c->ev1));
     HIPCK(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
     HIPCK(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    HIPCK(hipHostMalloc((void **)&c->h_gate, 64, hipHostMallocPortable | hipHostMallocMapped));
+    *c->h_gate = 1;
     for (auto &ps : c->pipe) {
         HIPCK(hipEventCreateWithFlags(&ps.ev_in, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&ps.ev_k, hipEventDisableTiming));
@@ -224,6 +229,7 @@ extern "C" void zpq_ctx_destroy(zpq_ctx *c)
         if (ps.ev_k) (void)hipEventDestroy(ps.ev_k);
         if (ps.ev_out) (void)hipEventDestroy(ps.ev_out);
     }
+    if (c->h_gate) (void)hipHostFree(c->h_gate);
     if (c->s_h2d) { (void)hipStreamSynchronize(c->s_h2d); (void)hipStreamDestroy(c->s_h2d); }
     if (c->s_d2h) { (void)hipStreamSynchronize(c->s_d2h); (void)hipStreamDestroy(c->s_d2h); }
     (void)hipFree(c->d_squash); (void)hipFree(c->d_stretch); (void)hipFree(c->d_dt2k);
@@ -298,6 +304,10 @@ struct BatchArgs {
     int32_t *trace; uint32_t ntrace;
     uint32_t *ctx_out;
     uint8_t *own_slot;   // zpq_block: use this slot instead of the pool
+    const uint32_t *gate_flag;   // striped upload (chain encode only): see DBatch
+    uint32_t gate_pos;
+    uint32_t *prog_counter;      // early download (chain decode only): see DBatch
+    uint32_t prog_pos;
 };
 
 // What a batch call will launch: kernel family, slot layout, resident slots and grid.
@@ -416,6 +426,11 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     B.first_byte = a.first_byte; B.status = a.status; B.trace = a.trace; B.ctx_out = a.ctx_out;
     B.squash = c->d_squash; B.stretch = c->d_stretch; B.dt = c->d_dt; B.dt2k = c->d_dt2k;
     B.ns = c->d_ns; B.stretch_c = c->d_stretch_c;
+    B.gate_flag = (want_chain && !decode) ? a.gate_flag : nullptr;
+    B.gate_pos = a.gate_pos;
+    if (a.gate_flag && !B.gate_flag) return ZPQ_E_INTERNAL;      // (a gated upload must meet a kernel that honours the gate)
+    B.prog_counter = (want_chain && decode) ? a.prog_counter : nullptr;   // (other kernels do not report: the host then copies after the kernel)
+    B.prog_pos = a.prog_pos;
 
     if (a.own_slot) {
         B.slots = a.own_slot;
@@ -451,7 +466,7 @@ extern "C" int zpq_encode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks
                                      const uint64_t *out_off, uint32_t *out_len, int32_t *status)
 {
     BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr, nullptr,
-                   status, nullptr, 0, nullptr, nullptr};
+                   status, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0};
     return run_batch(c, m, 0, a);
 }
 
@@ -461,7 +476,7 @@ extern "C" int zpq_decode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks
                                      uint32_t *final_code, uint32_t *first_byte, int32_t *status)
 {
     BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed, final_code,
-                   first_byte, status, nullptr, 0, nullptr, nullptr};
+                   first_byte, status, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0};
     return run_batch(c, m, 1, a);
 }
 
@@ -557,7 +572,7 @@ static void *pinned_device_ptr(const void *p)
 }
 
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
-                                                uint8_t *dst, const uint64_t *dst_off, int n);
+                                                uint8_t *dst, const uint64_t *dst_off, int n, uint32_t skip);
 
 // Batches of two or more blocks through host pointers, in ROUNDS of at most the resident capacity: round r+1 is
 // uploaded and round r-1 downloaded while round r is coded (three streams, two staging sets).  What replaces the
@@ -596,6 +611,8 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
         S.n = 0;
     };
     c->pipe[0].n = c->pipe[1].n = 0;
+    const uint32_t *gate_flag_dev = nullptr;
+    uint64_t stripe_L = 0, early_L = 0;
     for (int r = 0; r < nrounds; r++) {
         zpq_ctx::PipeSet &S = c->pipe[r & 1];
         const int b0 = r * per_round, b1 = (b0 + per_round < nblocks) ? b0 + per_round : nblocks, n = b1 - b0;
@@ -610,7 +627,28 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
         uint64_t *h_in = S.h_off, *h_out = S.h_off + (n + 1), *h_dst = S.h_off + 2 * (size_t)(n + 1);
         for (int k = 0; k <= n; k++) { h_in[k] = in_off[b0 + k] - in_base; h_out[k] = out_off[b0 + k] - out_base; h_dst[k] = out_off[b0 + k]; }
         // ---- upload on the copy-in stream
-        if (in_bytes) HIPCK(hipMemcpyAsync(S.in.p, in + in_base, in_bytes, hipMemcpyHostToDevice, c->s_h2d));
+        // One round cannot overlap its upload with its own coding by rounds -- every block starts at once.  But an
+        // encoder needs a block's bytes only as it gets to them (64 KiB take ~200 ms), so for a single round of equally
+        // long blocks from pinned memory the upload is STRIPED: the first 8 KiB of every block go first, the kernel
+        // starts, the rest follows while it runs; a lane that reaches the end of the first stripe waits for *h_gate.
+        bool striped = false;
+        const uint64_t stripe = 8192;
+        if (!decode && nrounds == 1 && in_pinned && P0.chain && !P0.sp && zpq_chain_has_hio(&m->d) && n >= 64 && !getenv("ZPQ_NO_STRIPE")) {
+            const uint64_t L = h_in[1] - h_in[0];
+            striped = L >= 4 * stripe && (L & 3u) == 0;
+            for (int k = 1; k < n && striped; k++) striped = h_in[k + 1] - h_in[k] == L;
+            if (striped) {
+                void *gate_dev = nullptr;
+                if (hipHostGetDevicePointer(&gate_dev, c->h_gate, 0) != hipSuccess) { (void)hipGetLastError(); striped = false; }
+                else {
+                    __atomic_store_n(c->h_gate, 0u, __ATOMIC_RELEASE);
+                    HIPCK(hipMemcpy2DAsync(S.in.p, L, in + in_base, L, stripe, (size_t)n, hipMemcpyHostToDevice, c->s_h2d));
+                    gate_flag_dev = (const uint32_t *)gate_dev;
+                    stripe_L = L;
+                }
+            }
+        }
+        if (!striped && in_bytes) HIPCK(hipMemcpyAsync(S.in.p, in + in_base, in_bytes, hipMemcpyHostToDevice, c->s_h2d));
         HIPCK(hipMemcpyAsync(S.inoff.p, h_in, offb, hipMemcpyHostToDevice, c->s_h2d));
         HIPCK(hipMemcpyAsync(S.outoff.p, h_out, offb, hipMemcpyHostToDevice, c->s_h2d));
         HIPCK(hipMemcpyAsync(S.dstoff.p, h_dst, offb, hipMemcpyHostToDevice, c->s_h2d));
@@ -626,9 +664,50 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
         a.out = (uint8_t *)S.out.p; a.out_off = (const uint64_t *)S.outoff.p; a.out_len = d_len;
         a.consumed = decode ? d_cons : nullptr; a.final_code = decode ? d_code : nullptr; a.first_byte = decode ? d_first : nullptr;
         a.status = (int32_t *)S.status.p;
+        if (striped) { a.gate_flag = gate_flag_dev; a.gate_pos = (uint32_t)stripe; }
+        // The mirror image for a decoder's output: every block reports when its first `early` bytes are stored (and
+        // visible to the copy engines); once all have, that stripe is copied out beside the kernel, which still has
+        // the last quarter of every block to decode.  Single round, pinned slabs of equal length and stride.
+        uint32_t early = 0;
+        uint32_t *prog_dev = nullptr;
+        if (decode && nrounds == 1 && out_dev_view && P0.chain && !P0.sp && zpq_chain_has_hio(&m->d) && n >= 64 && !getenv("ZPQ_NO_STRIPE")) {
+            const uint64_t L = h_out[1] - h_out[0];
+            bool uni = L >= 16384 && L <= 0x7FFFFFFFull;
+            for (int k = 1; k < n && uni; k++) uni = h_out[k + 1] - h_out[k] == L;
+            void *pd = nullptr;
+            if (uni && hipHostGetDevicePointer(&pd, c->h_gate + 8, 0) == hipSuccess) {
+                early = (uint32_t)(L / 4 * 3) & ~255u;
+                prog_dev = (uint32_t *)pd;
+                __atomic_store_n(c->h_gate + 8, 0u, __ATOMIC_RELEASE);
+                a.prog_counter = prog_dev; a.prog_pos = early;
+                early_L = L;
+            } else (void)hipGetLastError();
+        }
         rc = run_batch(c, m, decode, a);
+        if (striped) {
+            // the rest of every block, beside the running kernel; then the signal (whatever happened: a kernel left
+            // waiting for it would only end at its spin limit)
+            hipError_t e2 = rc == ZPQ_OK ? hipMemcpy2DAsync((uint8_t *)S.in.p + stripe, stripe_L, in + in_base + stripe, stripe_L, stripe_L - stripe,
+                                                            (size_t)n, hipMemcpyHostToDevice, c->s_h2d) : hipSuccess;
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->s_h2d);
+            __atomic_store_n(c->h_gate, 1u, __ATOMIC_RELEASE);
+            if (e2 != hipSuccess && rc == ZPQ_OK) { (void)hipDeviceSynchronize(); return ZPQ_E_NODEVICE; }
+        }
         if (rc != ZPQ_OK) { (void)hipDeviceSynchronize(); return rc; }
         HIPCK(hipEventRecord(S.ev_k, c->stream));
+        uint32_t skip = 0;
+        if (prog_dev) {
+            // wait (politely) until every block has reported, or the kernel has ended without all reports (a kernel
+            // family that does not report, an error): then nothing was copied early and everything goes the usual way
+            for (;;) {
+                if (__atomic_load_n(c->h_gate + 8, __ATOMIC_ACQUIRE) >= (uint32_t)n) { skip = early; break; }
+                if (hipEventQuery(S.ev_k) == hipSuccess) { skip = __atomic_load_n(c->h_gate + 8, __ATOMIC_ACQUIRE) >= (uint32_t)n ? early : 0; break; }
+                (void)hipGetLastError();
+                struct timespec ts = {0, 50000};
+                nanosleep(&ts, nullptr);
+            }
+            if (skip) HIPCK(hipMemcpy2DAsync(out + out_base, early_L, S.out.p, early_L, skip, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h));
+        }
         // ---- download on the copy-out stream
         HIPCK(hipStreamWaitEvent(c->s_d2h, S.ev_k, 0));
         HIPCK(hipMemcpyAsync(S.h_meta, d_len, u32b * 4, hipMemcpyDeviceToHost, c->s_d2h));
@@ -638,7 +717,7 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
             if (out_dev_view) {
                 // the GPU packs each block's produced bytes straight into the caller's (pinned) slab
                 hipLaunchKernelGGL(k_gather, dim3(n), dim3(256), 0, c->s_d2h, (const uint8_t *)S.out.p, (const uint64_t *)S.outoff.p,
-                                   (const uint32_t *)d_len, out_dev_view, (const uint64_t *)S.dstoff.p, n);
+                                   (const uint32_t *)d_len, out_dev_view, (const uint64_t *)S.dstoff.p, n, skip);
                 HIPCK(hipGetLastError());
             } else {
                 // pageable destination: the runtime stages this copy and the call returns only when it has run, so
@@ -720,14 +799,16 @@ extern "C" int zpq_decode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq
 // payload bytes cross PCIe.  One workgroup per block: bytes up to the destination's first 16-byte
 // boundary, then 16-byte stores fed by two aligned 16-byte loads funnel-shifted to the source's
 // misalignment, then the tail.
+// skip: leave out the first `skip` bytes of every block (they have been copied already)
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
-                                                uint8_t *dst, const uint64_t *dst_off, int n)
+                                                uint8_t *dst, const uint64_t *dst_off, int n, uint32_t skip)
 {
     const int b = blockIdx.x;
     if (b >= n) return;
-    const uint8_t *s = src + src_off[b];
-    uint8_t *d = dst + dst_off[b];
-    const uint32_t L = len[b];
+    if (len[b] <= skip) return;
+    const uint8_t *s = src + src_off[b] + skip;
+    uint8_t *d = dst + dst_off[b] + skip;
+    const uint32_t L = len[b] - skip;
     uint32_t head = (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u);
     if (head > L) head = L;
     for (uint32_t i = threadIdx.x; i < head; i += 256) d[i] = s[i];
@@ -761,7 +842,7 @@ extern "C" int zpq_gather_dev(zpq_ctx *c, int nblocks, const uint8_t *src, const
     if (nblocks == 0) return ZPQ_OK;
     if (!src_off || !len || !dst_off) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_gather, dim3(nblocks), dim3(256), 0, c->stream, src, src_off, len, dst, dst_off, nblocks);
+    hipLaunchKernelGGL(k_gather, dim3(nblocks), dim3(256), 0, c->stream, src, src_off, len, dst, dst_off, nblocks, 0u);
     return hipGetLastError() == hipSuccess ? ZPQ_OK : ZPQ_E_INTERNAL;
 }
 

@@ -151,7 +151,11 @@ struct BitCtx {
 // SP = some hash table of the model lives in a compact line store (levels 1 and 3-5; level 2's tables are smaller
 // than a store and stay dense).  Only SP kernels carry the store's code: its collision walk -- a divergent loop
 // with global loads inside take_prefetched -- cost the dense level-2 encode 17 % by its mere presence.
-template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG, bool SP>
+// HIO = the launch takes part in a striped host transfer (host_pipeline): the encoder waits ONCE, between two phases of
+// its byte loop, for the rest of its input; the decoder reports ONCE, there, that the first stripe of its output is
+// stored.  Only these instantiations carry that code: the mere presence of the wait inside the byte loop cost the
+// level-2 encoder 7 % (218 vs 204 ms), more than the overlap gains.
+template <bool DEC, bool SPEC, int NCH, bool MIXT, int GG, bool SP, bool HIO = false>
 __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg cfg)
 {
     constexpr int G = GG;            // shadows zpqc::G inside the kernel
@@ -1046,7 +1050,16 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u32 pend_pos = 0, pend_val = 0;
         const u32 skew_delay = SKEW ? (u32)li : 0u;
         const u32 iters = SKEW ? total + (u32)last : total;
-        for (u32 it = 0; it < iters; it++) {
+        // HIO: the byte loop runs in two phases with the host hand-shake between them (wave-uniform iteration counts: the
+        // encoder's lanes are at most 15 bytes apart, every decoder iteration after the PP byte stores one byte)
+        const u32 split = !HIO ? iters
+                               : (DEC ? (B.prog_counter ? B.prog_pos + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u) : iters)
+                                      : (B.gate_flag ? (B.gate_pos > 160u ? B.gate_pos - 160u : 0u) : iters));
+        u32 it = 0;
+        bool stop = false;
+        for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+        const u32 it_end = (HIO && phase == 0) ? min(iters, split) : iters;
+        for (; it < it_end; it++) {
             const u32 bi = it - skew_delay;
             // (lanes beyond the last component stay in step on dummy tables: masking them off made level 1 30 % slower --
             //  measured 286 vs 219 ms, cause not understood)
@@ -1077,7 +1090,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     }
                 }
                 eof = row_bcast(eof, row_base + last);
-                if (eof) break;
+                if (eof) { stop = true; break; }
             }
 
             X.c8 = 1; X.slot = 1;
@@ -1116,7 +1129,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     pend_pos = X.opos;
                     pend_val = byte;
                     X.opos++;                                 // uniform across the group when decoding
-                    if (X.opos > cap) break;
+                    if (X.opos > cap) { stop = true; break; }
                 }
             }
             }   // active
@@ -1130,6 +1143,28 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
             }
         }
+        if (HIO && phase == 0) {
+            if (!DEC && B.gate_flag) {
+                // striped upload: the rest of the input may still be crossing PCIe.  Wait for the host's signal (an acquire
+                // at system scope, so that nothing read afterwards is stale); bounded, so that a host that died cannot hang the GPU
+                u32 tries = 0;
+                while (__hip_atomic_load(B.gate_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++tries > (1u << 22)) { status = ZPQ_E_INTERNAL; break; }
+                }
+            }
+            if (DEC && B.prog_counter) {
+                // early download: this block's first stripe is decoded (or the block has ended).  Store the byte still
+                // pending, push this lane's stores and the L2's dirty lines out to memory, then count the block in
+                if (pend_store) { dst[pend_pos] = (u8)pend_val; pend_store = false; }
+                if (is_last && hyp == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                    __hip_atomic_fetch_add(B.prog_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        if (stop) break;
+        }   // phase
 
         if (DEC && pend_store) dst[pend_pos] = (u8)pend_val;
         // (the last nibble's row is not written back: the slot is re-initialised for the next block)
@@ -1291,11 +1326,20 @@ extern "C" const char *zpq_chain_kernel_name(const DModel *, int decode)
     return decode ? "k_chain<decode>" : "k_chain<encode>";
 }
 
+// striped host transfers (HIO kernels) exist for the dense short chains: levels 1 and 2
+extern "C" int zpq_chain_has_hio(const DModel *M)
+{
+    Cfg cfg;
+    return build_cfg(M, &cfg) && !cfg.sparse && (cfg.nch_spec == 2 || cfg.nch_spec == 3) ? 1 : 0;
+}
+
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
                                 hipStream_t stream)
 {
     Cfg cfg;
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
+    const bool hio = B->gate_flag != nullptr || B->prog_counter != nullptr;
+    if (hio && !zpq_chain_has_hio(hostM)) return ZPQ_E_INTERNAL;
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
     cfg.blocks_per_wg = blocks_per_wg;
     cfg.lds_dummy = blocks_per_wg * cfg.lds_per_block;
@@ -1308,8 +1352,18 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
         (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S_, N, MX, GGv, SPv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((zpqc::k_chain<D, S_, N, MX, GGv, SPv>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
     } while (0)
+#define ZPQ_LAUNCH_HIO(D, N)                                                                             \
+    do {                                                                                                 \
+        constexpr bool S_ = (D) ? (ZPQ_CHAIN_SPEC_DEC != 0) : (ZPQ_CHAIN_SPEC_ENC != 0);                 \
+        (void)hipFuncSetAttribute((const void *)zpqc::k_chain<D, S_, N, false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqc::k_chain<D, S_, N, false, 8, false, true>), dim3(nwg), dim3(threads), lds, stream, *B, cfg); \
+    } while (0)
 #define ZPQ_LAUNCH_SP(D, N, GGv)                                                                         \
-    do { if (cfg.sparse) ZPQ_LAUNCH(D, N, false, GGv, true); else ZPQ_LAUNCH(D, N, false, GGv, false); } while (0)
+    do {                                                                                                 \
+        if (cfg.sparse) ZPQ_LAUNCH(D, N, false, GGv, true);                                              \
+        else if (hio && ((N) == 2 || (N) == 3)) ZPQ_LAUNCH_HIO(D, ((N) == 2 ? 2 : 3));                   \
+        else ZPQ_LAUNCH(D, N, false, GGv, false);                                                        \
+    } while (0)
 #define ZPQ_DISPATCH(D)                                                                                  \
     do {                                                                                                 \
         switch (cfg.nch_spec) {                                                                          \
@@ -1326,6 +1380,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (decode) ZPQ_DISPATCH(true); else ZPQ_DISPATCH(false);
 #undef ZPQ_DISPATCH
 #undef ZPQ_LAUNCH_SP
+#undef ZPQ_LAUNCH_HIO
 #undef ZPQ_LAUNCH
     return ZPQ_OK;
 }

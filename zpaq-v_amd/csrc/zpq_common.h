@@ -84,6 +84,15 @@ struct DBatch {
     const int16_t *dt2k;         // [256]    predictor.v:99-106
     const uint8_t *ns;           // [1024]   statetable.v:15-57
     const uint32_t *stretch_c;   // [2048+64] compact stretch: (base<<16)|step bitmap, then exact ends
+    // Encode, striped upload (host_pipeline): bytes of a block's input at offset >= gate_pos may still be on their way
+    // over PCIe when the kernel starts; a lane reads them only once *gate_flag (pinned host memory) is non-zero.
+    const uint32_t *gate_flag;   // null = the whole input is resident
+    uint32_t gate_pos;
+    // Decode, early download (host_pipeline): a block that has STORED its first prog_pos output bytes (or has ended)
+    // makes them visible to the copy engines (release at system scope) and adds one to *prog_counter (pinned host
+    // memory); when the count reaches the number of blocks the host copies that stripe out beside the running kernel.
+    uint32_t prog_pos;
+    uint32_t *prog_counter;      // null = no progress reports
 };
 
 #define ZB_KEEP_STATE 0x100u     // do not re-initialise the slot (later segments of one block)
