@@ -36,8 +36,7 @@ extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supp
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
-                                hipStream_t stream);
-extern "C" const char *zpq_chain_kernel_name(const DModel *M, int decode);
+                                hipStream_t stream, const char **name_out);
 extern "C" int zpq_chain_has_hio(const DModel *M);   // kernels that take part in striped host transfers exist for this model
 extern "C" int zpq_launch_sha1(const uint8_t *in, const uint64_t *beg, const uint64_t *end, int n, uint8_t *out20, hipStream_t stream);
 
@@ -444,9 +443,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
 
     HIPCK(hipEventRecord(c->ev0, c->stream));
     if (want_chain && !a.own_slot) {
-        rc = zpq_launch_chain(&B, &M, decode, grid, bpw, c->stream);
+        const char *name = nullptr;
+        rc = zpq_launch_chain(&B, &M, decode, grid, bpw, c->stream, &name);
         if (rc != ZPQ_OK) return rc;
-        c->last_name = zpq_chain_kernel_name(&M, decode);
+        c->last_name = name;
     } else if (want_lanes) {
         rc = zpq_launch_lanes(&B, &M, decode, nslots, c->stream);
         if (rc != ZPQ_OK) return rc;

@@ -37,6 +37,7 @@
 #include "zpq_common.h"
 #include "zpq_vm.h"
 #include "zpq_host.h"
+#include "zpq_chain_cfg.h"
 
 // Measured on MI355X: the pipelined step wins for encode, for decode the step with
 // fewer instructions wins (both-candidate speculation was slower every time it was tried).
@@ -51,43 +52,6 @@
 #endif
 
 namespace zpqc {
-
-typedef int32_t i32;
-typedef uint32_t u32;
-typedef uint64_t u64;
-typedef uint8_t u8;
-typedef uint16_t u16;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int G = 16;          // lanes per ZPAQ block (= one DPP row)
-// (blocks per wave = 64 / lanes-per-block, fixed per kernel instantiation)
-constexpr int MAXW = 8;        // waves per workgroup upper bound
-
-// LDS layout of the shared read-only tables
-constexpr int LDS_STRETCH = 0;                   // u32[2048+128]
-constexpr int LDS_SQUASH = (2048 + 128) * 4;     // u16[4096]
-constexpr int LDS_NS = LDS_SQUASH + 4096 * 2;    // u8[1024]
-constexpr int LDS_STATE = LDS_NS + 1024;         // per-block state follows (16-B aligned)
-
-// HCOMP program shapes the kernel evaluates in registers instead of interpreting
-enum { VM_GENERIC = 0, VM_HASHCHAIN = 1, VM_LEVEL1 = 2 };
-
-struct Cfg {
-    int32_t n;                 // components
-    int32_t nisse_end;         // components 1..nisse_end-1 are ISSE (chain length incl. ICM)
-    int32_t has_mix2;          // last component is MIX2
-    int32_t blocks_per_wg;
-    int32_t lds_per_block;     // bytes
-    int32_t vm_kind;
-    int32_t g;                 // lanes per block chosen on the host (8 or 16)
-    int32_t nch_spec;          // compile-time specialisation picked on the host: chain length (0 = runtime path)
-    int32_t sparse;            // some component uses a compact line store
-    uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
-    int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
-    int32_t lds_mixw;          // byte offset inside the block's LDS state of u16[16]: the nibble's candidate MIX2 weights (decode)
-    uint16_t lds_off32[G];     // component c's u32 table inside the block's LDS state (cm | w0 + w1 low bits)
-    uint16_t lds_off8[G];      // ISSE c's u8 table (w1 bits 12..19); 0xFFFF = none
-};
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
@@ -1290,6 +1254,8 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
     return true;
 }
 
+bool zpq_chain_build_cfg(const DModel *M, zpqc::Cfg *cfg) { return build_cfg(M, cfg); }
+
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M)
 {
     Cfg cfg;
@@ -1321,11 +1287,6 @@ extern "C" int zpq_chain_max_wgs(const DModel *M, int cus)
     return cus;   // one workgroup per CU (LDS-bound)
 }
 
-extern "C" const char *zpq_chain_kernel_name(const DModel *, int decode)
-{
-    return decode ? "k_chain<decode>" : "k_chain<encode>";
-}
-
 // striped host transfers (HIO kernels) exist for the dense short chains: levels 1 and 2
 extern "C" int zpq_chain_has_hio(const DModel *M)
 {
@@ -1333,14 +1294,23 @@ extern "C" int zpq_chain_has_hio(const DModel *M)
     return build_cfg(M, &cfg) && !cfg.sparse && (cfg.nch_spec == 2 || cfg.nch_spec == 3) ? 1 : 0;
 }
 
+// zpq_pipe.hip: the wave-pipelined encoder of the chains without a MIX2
+extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg);
+extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream);
+
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
-                                hipStream_t stream)
+                                hipStream_t stream, const char **name_out)
 {
     Cfg cfg;
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     const bool hio = B->gate_flag != nullptr || B->prog_counter != nullptr;
     if (hio && !zpq_chain_has_hio(hostM)) return ZPQ_E_INTERNAL;
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
+    if (name_out) *name_out = decode ? "k_chain<decode>" : "k_chain<encode>";
+    if (!decode && !hio && zpq_pipe_applies(hostM, blocks_per_wg)) {
+        if (name_out) *name_out = "k_pipe<encode>";
+        return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream);
+    }
     cfg.blocks_per_wg = blocks_per_wg;
     cfg.lds_dummy = blocks_per_wg * cfg.lds_per_block;
     const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
