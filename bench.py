@@ -150,7 +150,7 @@ def roofline_of(A_minus_r, ratio, nb, size, enc_ms, dec_ms, names):
 
 def kernel_src_sha():
     h = hashlib.sha256()
-    for f in ("zpq_chain.hip", "zpq_common.h", "zpq_vm.h"):
+    for f in ("zpq_chain.hip", "zpq_pipe.hip", "zpq_chain_cfg.h", "zpq_common.h", "zpq_vm.h"):
         h.update(open(os.path.join(ROOT, "zpaq-v_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -275,7 +275,7 @@ def main():
         ratio = stats[0].item() / B_total
         enc_ms, dec_ms = rb.enc_ms[-1], rb.dec_ms[-1]
         roof = roofline_of(ALG_BYTES_PER_INPUT_BYTE_L.get(a.level, 195), ratio, nb, size, enc_ms, dec_ms,
-                           ("k_chain<encode>", "k_chain<decode>"))
+                           (rb.enc_name, rb.dec_name))
         traffic, tnote = measured_traffic(roof["kernel"], nb)
         roof["traffic"] = traffic
         roof["traffic_source"] = tnote
@@ -296,7 +296,7 @@ def main():
             "coded_bytes": int(stats[0].item()),
             "comp_MBps": round(nb * size / (enc_ms * 1e-3) / 1e6, 1),
             "decomp_MBps": round(nb * size / (dec_ms * 1e-3) / 1e6, 1),
-            "kernel_ms": {"k_chain<encode>": round(enc_ms, 3), "k_chain<decode>": round(dec_ms, 3)},
+            "kernel_ms": {rb.enc_name: round(enc_ms, 3), rb.dec_name: round(dec_ms, 3)},
             "resident_blocks": ctx.last_slots,
             "roofline": roof,
         }

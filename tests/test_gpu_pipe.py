@@ -1,0 +1,161 @@
+"""GPU parity of the wave-pipelined encoder (zpq_pipe.hip: one wave per component, lane = block; levels 1-3)
+against the CPU oracle and against the lane-per-component encoder (zpq_chain.hip, ZPQ_ENC_PIPE=0), through the C ABI."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import workload as W
+
+sys.path.insert(0, os.path.dirname(__file__))
+from test_gpu_chain import mixed_blocks  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=None, cap=None):
+    kw = {}
+    if flags is not None:
+        kw["flags"] = flags
+    if cap is not None:
+        kw["cap"] = cap
+    monkeypatch.delenv("ZPQ_ENC_PIPE", raising=False)
+    a, sa, la = gpu_ctx.encode_blocks(model, blocks, **kw)
+    assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
+    monkeypatch.setenv("ZPQ_ENC_PIPE", "0")
+    b, sb, lb = gpu_ctx.encode_blocks(model, blocks, **kw)
+    assert gpu_ctx.last_kernel_name == "k_chain<encode>"
+    monkeypatch.delenv("ZPQ_ENC_PIPE", raising=False)
+    assert list(sa) == list(sb)
+    for i in range(len(blocks)):                 # (a refused block's bytes are unspecified)
+        if sa[i] == 0:
+            assert int(la[i]) == int(lb[i]) and a[i] == b[i], i
+    return a, sa
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_both_encoders_agree_with_the_oracle(zpq, gpu_ctx, monkeypatch, level):
+    """Ragged batch (empty, one byte, sizes around a dword and a nibble row), with and without the PP byte, more
+    blocks than one workgroup holds."""
+    rnd = random.Random(4000 + level)
+    model = zpq.Model(level=level)
+    blocks = mixed_blocks(rnd, 75, [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 1000, 3000])
+    for flags, pp in ((zpq.FLAG_PP, True), (0, False)):
+        coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=flags)
+        assert (status == 0).all()
+        assert coded == O.encode_blocks(model.header, blocks, pp=pp, nthreads=4)
+
+
+def small_table_header(level, bits):
+    """The level's header with every hash table shrunk to 64 << bits bytes: contexts of neighbouring nibbles then share
+    lines and rows all the time, which is what the encoder's register forwarding (the rows of the two nibbles finished
+    between a request and its use) has to get right."""
+    h = bytearray(O.level_header(level))
+    sz = [0, 2, 3, 2, 3, 4, 6, 6, 3, 5]
+    p = 5
+    for _ in range(h[4]):
+        if h[p] in (3, 8):
+            h[p + 1] = bits
+        p += sz[h[p]]
+    return bytes(h)
+
+
+@pytest.mark.parametrize("level,bits", [(1, 0), (1, 2), (2, 0), (2, 1), (2, 3), (3, 0), (3, 2)])
+def test_row_forwarding_under_heavy_aliasing(zpq, gpu_ctx, monkeypatch, level, bits):
+    header = small_table_header(level, bits)
+    model = zpq.Model(header=header)
+    assert model.has_fast_path
+    rnd = random.Random(17 * level + bits)
+    blocks = [bytes(3000), b"a" * 2500, b"ab" * 1500, b"abc" * 1000, b"abcd" * 700, bytes(range(256)) * 8,
+              bytes(rnd.getrandbits(8) for _ in range(3000)), bytes(rnd.choice(b"01") for _ in range(3000)),
+              b"\x00\x10" * 1200, b"\x0f\xf0\x00" * 900, b"", b"x"]
+    coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks)
+    assert (status == 0).all()
+    assert coded == O.encode_blocks(header, blocks, nthreads=4)
+    dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=4096)
+    assert (status == 0).all() and dec == blocks
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_rounds_and_partial_workgroups(zpq, gpu_ctx, monkeypatch, level):
+    """Fewer slots than blocks: every lane of the pipeline codes several blocks one after the other (tables, links and
+    coder state must start clean), the last round and the last workgroup are partly idle."""
+    model = zpq.Model(level=level)
+    rnd = random.Random(99 + level)
+    blocks = mixed_blocks(rnd, 83, [0, 1, 300, 1200, 2048])
+    want = O.encode_blocks(model.header, blocks, nthreads=4)
+    monkeypatch.setenv("ZPQ_SPARSE_MODE", "never")
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 19 * model.state_bytes + 1000)
+    try:
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name == "k_pipe<encode>" and gpu_ctx.last_slots == 19
+        assert (status == 0).all() and coded == want
+    finally:
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_line_store_through_the_pipeline(zpq, gpu_ctx, monkeypatch, level):
+    """The compact line store under the wave-pipelined encoder: probing, claims, displaced lines (a small forced
+    store), and the refusal of a block that needs more lines than promised."""
+    model = zpq.Model(level=level)
+    rnd = random.Random(31 + level)
+    blocks = mixed_blocks(rnd, 40, [0, 1, 17, 300, 1000, 1900])
+    want = O.encode_blocks(model.header, blocks, nthreads=4)
+    monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "13")
+    coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks)
+    assert (status == 0).all() and coded == want
+    monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "10")
+    big = [bytes(rnd.getrandbits(8) for _ in range(3000)), bytes(100)]
+    _, status = encode_both(zpq, gpu_ctx, monkeypatch, model, big)
+    assert status[0] == -4 and status[1] == 0
+
+
+def test_output_overflow_is_reported_not_written(zpq, gpu_ctx, monkeypatch):
+    model = zpq.Model(level=2)
+    rnd = random.Random(5)
+    data = [bytes(rnd.getrandbits(8) for _ in range(2000)), bytes(50)]
+    coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, data, cap=100)
+    assert status[0] == -7 and status[1] == 0
+    assert coded[1] == O.encode_blocks(model.header, data[1:])[0]
+
+
+@pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024)])
+def test_full_size_batches(zpq, gpu_ctx, level, nb):
+    """BASELINE.json's shapes (level 1: 4096 x 64 KiB, level 2: 8192 x 64 KiB): sampled blocks against the oracle,
+    every block through the round trip."""
+    import torch
+    model = zpq.Model(level=level)
+    size = 65536
+    arr = W.make_blocks_fast(nb, size)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(arr.reshape(-1)).to(dev)
+    cap = size + size // 8 + 1024
+    in_off = torch.arange(nb + 1, dtype=torch.int64, device=dev) * size
+    out_off = torch.arange(nb + 1, dtype=torch.int64, device=dev) * cap
+    d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(nb, dtype=torch.int32, device=dev)
+    gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
+                              out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
+    gpu_ctx.sync()
+    assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
+    assert bool((d_st == 0).all())
+    lens = d_len.cpu().numpy()
+    outc = d_out.cpu().numpy()
+    rnd = random.Random(level)
+    sample = sorted(set([0, 1, 2, 3, nb - 1, nb - 2, nb - 3, nb - 4] + [rnd.randrange(nb) for _ in range(16)]))
+    want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=8, slack=cap)
+    for i, w in zip(sample, want):
+        assert outc[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+    d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
+    d_dlen = torch.zeros(nb, dtype=torch.int32, device=dev)
+    aux = [torch.zeros(nb, dtype=torch.int32, device=dev) for _ in range(4)]
+    gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
+                              in_off.data_ptr(), d_dlen.data_ptr(), aux[0].data_ptr(), aux[1].data_ptr(),
+                              aux[2].data_ptr(), aux[3].data_ptr())
+    gpu_ctx.sync()
+    assert bool((aux[3] == 0).all()) and bool(torch.equal(d_dec, d_in)) and bool((d_dlen == size).all())

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_src_sha():                      # the same fingerprint bench.py computes: a profile is only cited for the source it was taken on
     h = hashlib.sha256()
-    for f in ("zpq_chain.hip", "zpq_common.h", "zpq_vm.h"):
+    for f in ("zpq_chain.hip", "zpq_pipe.hip", "zpq_chain_cfg.h", "zpq_common.h", "zpq_vm.h"):
         h.update(open(os.path.join(ROOT, "zpaq-v_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -23,19 +23,22 @@ def commit():
     except Exception:
         return os.environ.get("ZPQ_COMMIT", "")
 LAUNCHES = 2
+enc_name = "k_chain<encode>"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_chain" not in k:
+        if "k_chain" not in k and "k_pipe" not in k:
             continue
         role = "decode" if "k_chain<true" in k else "encode"
+        if role == "encode":
+            enc_name = "k_pipe<encode>" if "k_pipe" in k else "k_chain<encode>"
         agg[role][r["Counter_Name"]] += float(r["Counter_Value"]) / LAUNCHES
 pmc = {}
 for role in ("encode", "decode"):
     c = agg[role]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        pmc["k_chain<%s>" % role] = {
+        pmc[enc_name if role == "encode" else "k_chain<decode>"] = {
             "FETCH_SIZE_KB_per_launch": c["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": c["WRITE_SIZE"],
             "hbm_bytes_per_launch": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
             "hbm_bytes_per_launch_fetch_x2": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
@@ -54,6 +57,7 @@ sq = {role: {k: v for k, v in agg[role].items() if k.startswith("SQ_")} for role
 if any(sq.values()):
     sq["_kernel_src_sha"] = kernel_src_sha()
     sq["_commit"] = commit()
+    sq["_encode_kernel"] = enc_name
     sq["_note"] = "per launch, summed over the 1024 waves; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"
     json.dump(sq, open(dst + "_sq_counters.json", "w"), indent=1)
 print(json.dumps({"pmc": {k: v for k, v in pmc.items() if not k.startswith("_note")}, "sq_keys": sorted(k for k in sq.get("decode", {}))}, indent=1)[:1500])

@@ -1307,7 +1307,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (hio && !zpq_chain_has_hio(hostM)) return ZPQ_E_INTERNAL;
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
     if (name_out) *name_out = decode ? "k_chain<decode>" : "k_chain<encode>";
-    if (!decode && !hio && zpq_pipe_applies(hostM, blocks_per_wg)) {
+    if (!decode && zpq_pipe_applies(hostM, blocks_per_wg)) {
         if (name_out) *name_out = "k_pipe<encode>";
         return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream);
     }

@@ -41,6 +41,19 @@ __device__ __forceinline__ uint32_t mul_shr16(uint32_t range, uint32_t p16)   //
 // LDS traffic of this wave done, then the workgroup barrier (no wait for global memory: the row prefetch stays in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Striped upload (host_pipeline, DBatch::gate_flag): the rest of the input may still be crossing PCIe.  Wait for the
+// host's signal (an acquire at system scope, so that nothing read afterwards is stale); bounded, so that a host that
+// died cannot hang the GPU.  false = gave up.
+__device__ __forceinline__ bool gate_wait(const uint32_t *flag)
+{
+    u32 tries = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __builtin_amdgcn_s_sleep(64);
+        if (++tries > (1u << 22)) return false;
+    }
+    return true;
+}
+
 // LDS behind the per-block state: the links between the stages and the per-stage status words
 struct PipeLds {
     int32_t link_off;    // uint4 link[NCH][2][blocks_per_wg]
@@ -58,6 +71,7 @@ struct StageArgs {
     u8 *slot, *my;
     const u8 *src;
     u32 nin, total, iters;
+    u32 split;           // HIO: iterations before the gate
     u8 *dst;
     u32 cap;
     u32 blk;
@@ -115,7 +129,7 @@ struct Row {
 };
 
 // ------------------------------------------------------------------ a component stage
-template <int NCH, bool SP, bool IS_ICM, bool IS_LAST>
+template <int NCH, bool SP, bool HIO, bool IS_ICM, bool IS_LAST>
 __device__ __forceinline__ void comp_loop(const StageArgs &S)
 {
     const DBatch &B = *S.B;
@@ -405,7 +419,12 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
             reqY = request(0u, 16u | (ch0 >> 4));
         }
     }
-    for (u32 it = 0; it < S.iters; it++) {
+    // HIO: the byte loop runs in two phases with the wait for the host between them (the wait inside the loop would
+    // cost every iteration; zpq_chain.hip measured 7 %).  No stage has then read beyond S.split + 16 bytes of a block.
+    u32 it = 0;
+    for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+    const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
+    for (; it < it_end; it++) {
         const u32 bi = it - (u32)ci;
 #ifdef ZPP_DEBUG_NO_COMP   // timing experiment only
         if (false) {
@@ -443,6 +462,8 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         }
         lds_barrier();
     }
+    if (HIO && phase == 0 && B.gate_flag && !gate_wait(B.gate_flag)) status = ZPQ_E_INTERNAL;
+    }   // phase
     // (the last nibbles' rows are not written back: the slot is re-initialised for the next block)
     if (S.lane < S.bpw) reinterpret_cast<i32 *>(lds + S.L.stat_off)[ci * S.bpw + S.lane] = status;
 #undef ZPP_LOAD_ROWS
@@ -468,13 +489,16 @@ struct Coder {
     }
 };
 
-template <int NCH>
+template <int NCH, bool HIO>
 __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
 {
     u8 *const lds = S.lds;
     const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NCH - 1) * 2 * S.bpw + S.lane;
     const u32 total = S.total;
-    for (u32 it = 0; it < S.iters; it++) {
+    u32 it = 0;
+    for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+    const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
+    for (; it < it_end; it++) {
         const u32 bi = it - (u32)NCH;
 #ifdef ZPP_DEBUG_NO_CODER   // timing experiment only
         if (false) {
@@ -503,9 +527,10 @@ __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
         }
         lds_barrier();
     }
+    }   // phase (the coder reads no input: nothing to wait for)
 }
 
-template <int NCH, bool SP>
+template <int NCH, bool SP, bool HIO>
 __global__ void __launch_bounds__(64 * (NCH + 1)) k_pipe(const DBatch B, const Cfg cfg, const PipeLds L)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -580,13 +605,15 @@ __global__ void __launch_bounds__(64 * (NCH + 1)) k_pipe(const DBatch B, const C
         if (wave == 0) atomicMax(misc, S.total);
         __syncthreads();
         S.iters = *misc + (u32)NCH;
+        // (the ICM is the stage furthest ahead: in iteration `it` it is at input byte <= it and holds <= 12 bytes more)
+        S.split = (HIO && B.gate_flag) ? (B.gate_pos > 64u ? B.gate_pos - 64u : 0u) : S.iters;
 
         Coder X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
-        if (wave == 0) comp_loop<NCH, SP, true, false>(S);
-        else if (wave < NCH - 1) comp_loop<NCH, SP, false, false>(S);
-        else if (wave == NCH - 1) comp_loop<NCH, SP, false, true>(S);
-        else coder_loop<NCH>(S, X);
+        if (wave == 0) comp_loop<NCH, SP, HIO, true, false>(S);
+        else if (wave < NCH - 1) comp_loop<NCH, SP, HIO, false, false>(S);
+        else if (wave == NCH - 1) comp_loop<NCH, SP, HIO, false, true>(S);
+        else coder_loop<NCH, HIO>(S, X);
         __syncthreads();
         if (wave == NCH && active) {
             // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
@@ -641,20 +668,21 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     Cfg cfg;
     if (!zpq_chain_build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     if (!zpq_pipe_applies(hostM, blocks_per_wg)) return ZPQ_E_INTERNAL;
-    if (B->gate_flag) return ZPQ_E_INTERNAL;                 // (striped uploads meet zpq_chain.hip's HIO encoder)
+    const bool hio = B->gate_flag != nullptr;
+    if (hio && cfg.sparse) return ZPQ_E_INTERNAL;            // (striped uploads: dense levels 1-2, see zpq_chain_has_hio)
     cfg.blocks_per_wg = blocks_per_wg;
     zpqp::PipeLds L;
     size_t lds = 0;
     if (!pipe_layout(cfg, blocks_per_wg, &L, &lds)) return ZPQ_E_INTERNAL;
-#define ZPP_LAUNCH(N, SPv)                                                                                           \
+#define ZPP_LAUNCH(N, SPv, HIOv)                                                                                     \
     do {                                                                                                             \
-        (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, SPv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((zpqp::k_pipe<N, SPv>), dim3(nwg), dim3(64 * ((N) + 1)), lds, stream, *B, cfg, L);        \
+        (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, SPv, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqp::k_pipe<N, SPv, HIOv>), dim3(nwg), dim3(64 * ((N) + 1)), lds, stream, *B, cfg, L);  \
     } while (0)
     switch (cfg.nch_spec) {
-    case 2: if (cfg.sparse) ZPP_LAUNCH(2, true); else ZPP_LAUNCH(2, false); break;
-    case 3: if (cfg.sparse) ZPP_LAUNCH(3, true); else ZPP_LAUNCH(3, false); break;
-    case 5: if (cfg.sparse) ZPP_LAUNCH(5, true); else ZPP_LAUNCH(5, false); break;
+    case 2: if (cfg.sparse) ZPP_LAUNCH(2, true, false); else if (hio) ZPP_LAUNCH(2, false, true); else ZPP_LAUNCH(2, false, false); break;
+    case 3: if (cfg.sparse) ZPP_LAUNCH(3, true, false); else if (hio) ZPP_LAUNCH(3, false, true); else ZPP_LAUNCH(3, false, false); break;
+    case 5: if (hio) return ZPQ_E_INTERNAL; if (cfg.sparse) ZPP_LAUNCH(5, true, false); else ZPP_LAUNCH(5, false, false); break;
     default: return ZPQ_E_INTERNAL;
     }
 #undef ZPP_LAUNCH
