@@ -46,7 +46,7 @@ def test_chain_matches_golden_streams(zpq, gpu_ctx, level):
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         flags = zpq.FLAG_PP if mode == "pp" else 0
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=flags)
-        assert gpu_ctx.last_kernel_name == ("k_pipe<encode>" if level <= 3 else "k_chain<encode>")
+        assert gpu_ctx.last_kernel_name == ("k_pipe<encode>" if level <= 3 and len(blocks) >= 12 else "k_chain<encode>")
         assert (status == 0).all()
         for k, c in zip(ks, coded):
             assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k

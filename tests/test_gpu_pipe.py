@@ -23,6 +23,7 @@ def encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=None, cap=None):
     if cap is not None:
         kw["cap"] = cap
     monkeypatch.delenv("ZPQ_ENC_PIPE", raising=False)
+    assert len(blocks) >= 12                     # (smaller batches stay with the lane-per-component encoder)
     a, sa, la = gpu_ctx.encode_blocks(model, blocks, **kw)
     assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
     monkeypatch.setenv("ZPQ_ENC_PIPE", "0")
@@ -109,18 +110,29 @@ def test_line_store_through_the_pipeline(zpq, gpu_ctx, monkeypatch, level):
     coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks)
     assert (status == 0).all() and coded == want
     monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "10")
-    big = [bytes(rnd.getrandbits(8) for _ in range(3000)), bytes(100)]
+    big = [bytes(rnd.getrandbits(8) for _ in range(3000))] + [bytes(100)] * 12
     _, status = encode_both(zpq, gpu_ctx, monkeypatch, model, big)
-    assert status[0] == -4 and status[1] == 0
+    assert status[0] == -4 and (status[1:] == 0).all()
 
 
 def test_output_overflow_is_reported_not_written(zpq, gpu_ctx, monkeypatch):
     model = zpq.Model(level=2)
     rnd = random.Random(5)
-    data = [bytes(rnd.getrandbits(8) for _ in range(2000)), bytes(50)]
+    data = [bytes(rnd.getrandbits(8) for _ in range(2000))] + [bytes(50 + i) for i in range(12)]
     coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, data, cap=100)
-    assert status[0] == -7 and status[1] == 0
-    assert coded[1] == O.encode_blocks(model.header, data[1:])[0]
+    assert status[0] == -7 and (status[1:] == 0).all()
+    assert coded[1:] == O.encode_blocks(model.header, data[1:])
+
+
+def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
+    """A component wave with only a few active lanes runs at half speed: fewer than 12 resident blocks
+    are coded by zpq_chain.hip's encoder; 12 and more by the pipeline, regrouped evenly over its workgroups."""
+    model = zpq.Model(level=2)
+    for n, name in ((1, "k_chain<encode>"), (11, "k_chain<encode>"), (12, "k_pipe<encode>"), (37, "k_pipe<encode>")):
+        blocks = [bytes(W.make_block(b, 700 + 13 * b)) for b in range(n)]
+        coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name == name and (status == 0).all()
+        assert coded == O.encode_blocks(model.header, blocks, nthreads=4)
 
 
 @pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024)])

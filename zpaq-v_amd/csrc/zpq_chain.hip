@@ -1270,6 +1270,11 @@ static int plan_blocks_per_wg(const Cfg &cfg, int nblocks, int cus)
     int want = (nblocks + cus - 1) / cus;
     want = (want + bpwave - 1) / bpwave * bpwave;
     if (want < bpwave) want = bpwave;
+    {
+        const char *ev = getenv("ZPQ_CHAIN_BPW");         // tuning knob: at least this many blocks per workgroup
+        const int floor_ = ev ? atoi(ev) / bpwave * bpwave : 0;
+        if (floor_ > want) want = floor_;
+    }
     return want < cfg.blocks_per_wg ? want : cfg.blocks_per_wg;
 }
 
@@ -1295,7 +1300,7 @@ extern "C" int zpq_chain_has_hio(const DModel *M)
 }
 
 // zpq_pipe.hip: the wave-pipelined encoder of the chains without a MIX2
-extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg);
+extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots);
 extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream);
 
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
@@ -1307,7 +1312,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (hio && !zpq_chain_has_hio(hostM)) return ZPQ_E_INTERNAL;
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
     if (name_out) *name_out = decode ? "k_chain<decode>" : "k_chain<encode>";
-    if (!decode && zpq_pipe_applies(hostM, blocks_per_wg)) {
+    if (!decode && zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) {
         if (name_out) *name_out = "k_pipe<encode>";
         return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream);
     }

@@ -650,8 +650,10 @@ static bool pipe_layout(const Cfg &cfg, int bpw, zpqp::PipeLds *L, size_t *lds_b
 
 // The wave-pipelined encoder exists for the dense and line-store chains of levels 1-3.  ZPQ_ENC_PIPE=0 keeps the
 // lane-per-component encoder (tests compare the two).
-extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg)
+// (a batch of fewer than 12 resident blocks stays with the lane-per-component encoder: see zpq_launch_pipe)
+extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots)
 {
+    if (nslots < 12) return 0;
     const char *ev = getenv("ZPQ_ENC_PIPE");
     if (ev && atoi(ev) == 0) return 0;
     Cfg cfg;
@@ -667,13 +669,28 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
 {
     Cfg cfg;
     if (!zpq_chain_build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
-    if (!zpq_pipe_applies(hostM, blocks_per_wg)) return ZPQ_E_INTERNAL;
+    if (!zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) return ZPQ_E_INTERNAL;
+    // Slot s is lane s % B of workgroup s / B for ANY B, so this kernel regroups the plan's slots: at least 16 per
+    // workgroup where the batch has them, and evenly, so that no workgroup is left with a handful.  A component wave
+    // with <= 8 active lanes runs at less than half speed (one workgroup alone on the GPU: 8 blocks 250 ms, 12 blocks
+    // 112 ms, 32 blocks 108 ms; same instruction count, ten times the SQ_WAIT_INST_ANY cycles -- cause not understood).
+    {
+        const int nslots = B->nslots;
+        const int cap = cfg.blocks_per_wg;
+        int per = blocks_per_wg < 16 ? (cap < 16 ? cap : 16) : blocks_per_wg;
+        nwg = (nslots + per - 1) / per;
+        blocks_per_wg = (nslots + nwg - 1) / nwg;
+    }
     const bool hio = B->gate_flag != nullptr;
     if (hio && cfg.sparse) return ZPQ_E_INTERNAL;            // (striped uploads: dense levels 1-2, see zpq_chain_has_hio)
     cfg.blocks_per_wg = blocks_per_wg;
     zpqp::PipeLds L;
     size_t lds = 0;
     if (!pipe_layout(cfg, blocks_per_wg, &L, &lds)) return ZPQ_E_INTERNAL;
+    // A small batch has few blocks per workgroup and would fit several workgroups into one CU's LDS -- whose waves
+    // would then share SIMDs while other CUs idle (measured: 1024 blocks 254 ms instead of 114).  Asking for more than
+    // half of the LDS keeps it at one workgroup per CU, one wave per SIMD.
+    if (lds < 81 * 1024) lds = 81 * 1024;
 #define ZPP_LAUNCH(N, SPv, HIOv)                                                                                     \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, SPv, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
