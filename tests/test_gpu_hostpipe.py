@@ -142,3 +142,57 @@ def test_striped_upload_equals_plain_upload(zpq, gpu_ctx, monkeypatch):
                                  st.ctypes.data)
         assert rc == 0 and (st == 0).all() and (olen == size).all() and (first == 0).all()
         assert pin_out.array.tobytes() == b"".join(blocks)
+
+
+def test_c5_whole_workload_through_one_context(zpq, gpu_ctx):
+    """BASELINE.json's C5 at its stated TOTAL size -- level 2, 65 536 x 64 KiB = 4 GiB -- on the one GPU a test has:
+    eight rounds of the resident capacity through the host-pointer calls (pinned buffers, transfers of neighbouring
+    rounds overlapped with coding).  Size-independent properties: every block decodes back to its input; a block's coded
+    bytes do not depend on where in the batch (which round, which slot, which workgroup) it was coded -- the generator
+    repeats each text block every 256 positions; sampled blocks of every class equal the oracle's stream."""
+    L = zpq.lib()
+    model = zpq.Model(level=2)
+    nb, size = 65536, 65536
+    cap = size + size // 8 + 1024
+    p_src = zpq.PinnedArray(nb * size)
+    src2d = p_src.array.reshape(nb, size)
+    for b0 in range(0, nb, 4096):
+        src2d[b0:b0 + 4096] = W.make_blocks_fast(4096, size, start=b0)
+    in_off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(size)
+    out_off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(cap)
+    p_out = zpq.PinnedArray(nb * cap)
+    olen = np.zeros(nb, dtype=np.uint32); st = np.full(nb, -99, dtype=np.int32)
+    rc = L.zpq_encode_blocks(gpu_ctx.h, model.h, nb, p_src.array.ctypes.data, in_off.ctypes.data, zpq.FLAG_PP,
+                             p_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
+    assert rc == 0 and (st == 0).all()
+    assert gpu_ctx.last_slots == 8192                      # eight rounds of one resident batch each
+    out = p_out.array
+
+    def coded(i):
+        return out[i * cap:i * cap + int(olen[i])].tobytes()
+
+    # position independence: text block b is pool entry (b // 4) % 64, i.e. identical every 256 blocks
+    for b in (2, 6, 250):
+        ref = coded(b)
+        for k in range(1, nb // 256, 7):
+            assert coded(b + 256 * k) == ref, (b, k)
+    rnd = random.Random(65536)
+    sample = sorted({0, 1, 2, 3, 8191, 8192, nb - 4, nb - 3, nb - 2, nb - 1} | {rnd.randrange(nb) for _ in range(22)})
+    want = O.encode_blocks(model.header, [src2d[i].tobytes() for i in sample], nthreads=8, slack=cap)
+    for i, w in zip(sample, want):
+        assert coded(i) == w, i
+    # decode from the packed streams, as an archive holds them
+    c_off = np.zeros(nb + 1, dtype=np.uint64)
+    c_off[1:] = np.cumsum(olen.astype(np.uint64))
+    p_cod = zpq.PinnedArray(int(c_off[-1]) + 16)
+    for i in range(nb):
+        p_cod.array[int(c_off[i]):int(c_off[i + 1])] = out[i * cap:i * cap + int(olen[i])]
+    p_out.free()
+    p_dec = zpq.PinnedArray(nb * size)
+    dlen = np.zeros(nb, dtype=np.uint32); dst = np.full(nb, -99, dtype=np.int32)
+    rc = L.zpq_decode_blocks(gpu_ctx.h, model.h, nb, p_cod.array.ctypes.data, c_off.ctypes.data, zpq.FLAG_PP,
+                             p_dec.array.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, None, None, None, dst.ctypes.data)
+    assert rc == 0 and (dst == 0).all() and (dlen == size).all()
+    assert np.array_equal(p_dec.array, p_src.array)
+    for pa in (p_src, p_cod, p_dec):
+        pa.free()
