@@ -151,6 +151,7 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
     d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
     d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
     d_st = torch.zeros(nb, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                             # order torch's fills before the ctx stream's kernels
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     gpu_ctx.sync()
@@ -166,6 +167,7 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
     d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
     d_dlen = torch.zeros(nb, dtype=torch.int32, device=dev)
     aux = [torch.zeros(nb, dtype=torch.int32, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
     gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
                               in_off.data_ptr(), d_dlen.data_ptr(), aux[0].data_ptr(), aux[1].data_ptr(),
                               aux[2].data_ptr(), aux[3].data_ptr())
