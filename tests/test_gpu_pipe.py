@@ -173,3 +173,16 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
                               aux[2].data_ptr(), aux[3].data_ptr())
     gpu_ctx.sync()
     assert bool((aux[3] == 0).all()) and bool(torch.equal(d_dec, d_in)) and bool((d_dlen == size).all())
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_blocks_larger_than_64k(zpq, gpu_ctx, monkeypatch, level):
+    """Blocks of several hundred KiB (tables wrap around many times, positions pass 2^16, lanes end far apart)."""
+    model = zpq.Model(level=level)
+    rnd = random.Random(level)
+    blocks = [bytes(W.make_block(b, rnd.choice([70000, 131073, 262144, 400001]))) for b in range(13)]
+    coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks)
+    assert (status == 0).all()
+    assert coded == O.encode_blocks(model.header, blocks, nthreads=8)
+    dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=400100)
+    assert (status == 0).all() and dec == blocks
