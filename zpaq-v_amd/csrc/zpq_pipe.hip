@@ -671,9 +671,10 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     if (!zpq_chain_build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     if (!zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) return ZPQ_E_INTERNAL;
     // Slot s is lane s % B of workgroup s / B for ANY B, so this kernel regroups the plan's slots: at least 16 per
-    // workgroup where the batch has them, and evenly, so that no workgroup is left with a handful.  A component wave
-    // with <= 8 active lanes runs at less than half speed (one workgroup alone on the GPU: 8 blocks 250 ms, 12 blocks
-    // 112 ms, 32 blocks 108 ms; same instruction count, ten times the SQ_WAIT_INST_ANY cycles -- cause not understood).
+    // workgroup where the batch has them, and evenly, so that no workgroup is left with a handful.  A wave that LIVES
+    // on <= 8 active lanes issues VALU code at a third of its speed on this GPU (tools/micro/lanes.hip; one workgroup
+    // alone: 8 blocks 250 ms, 12 blocks 112 ms, 32 blocks 108 ms; same instruction count, ten times the
+    // SQ_WAIT_INST_ANY cycles), and here a lane is a block.
     {
         const int nslots = B->nslots;
         const int cap = cfg.blocks_per_wg;
