@@ -46,7 +46,7 @@ def test_chain_matches_golden_streams(zpq, gpu_ctx, level):
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         flags = zpq.FLAG_PP if mode == "pp" else 0
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=flags)
-        assert gpu_ctx.last_kernel_name == ("k_pipe<encode>" if level <= 3 and len(blocks) >= 12 else "k_chain<encode>")
+        assert gpu_ctx.last_kernel_name == ("k_pipe<encode>" if len(blocks) >= 12 else "k_chain<encode>")
         assert (status == 0).all()
         for k, c in zip(ks, coded):
             assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k
@@ -374,7 +374,7 @@ def test_mix2_levels_ragged_batch_with_slot_reuse(zpq, gpu_ctx, level):
 
 
 @pytest.mark.parametrize("level", [4, 5])
-def test_mix2_weight_aliasing_stress(zpq, gpu_ctx, level):
+def test_mix2_weight_aliasing_stress(zpq, gpu_ctx, monkeypatch, level):
     """The MIX2 weight index is a hash: consecutive nibbles may reach the same weight under different slots (and so,
     in the decoder, under different lanes).  Shrinking the level's MIX2 table to 256 entries makes that happen all
     the time; the decoder must then forward the trained value instead of re-reading memory."""
@@ -391,7 +391,10 @@ def test_mix2_weight_aliasing_stress(zpq, gpu_ctx, level):
     blocks = [bytes(W.make_block(b, 3000 + 500 * (b % 3))) for b in range(12)]
     want = O.encode_blocks(header, blocks, nthreads=4)
     coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
-    assert gpu_ctx.last_kernel_name == "k_chain<encode>" and (status == 0).all() and coded == want
+    assert gpu_ctx.last_kernel_name == "k_pipe<encode>" and (status == 0).all() and coded == want
+    monkeypatch.setenv("ZPQ_ENC_PIPE", "0")                 # the lane-per-component encoder (weights in registers per byte)
+    coded2, status, _ = gpu_ctx.encode_blocks(model, blocks)
+    assert gpu_ctx.last_kernel_name == "k_chain<encode>" and (status == 0).all() and coded2 == want
     dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, coded, cap=8192)
     assert (status == 0).all() and dec == blocks
 

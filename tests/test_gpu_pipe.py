@@ -1,4 +1,4 @@
-"""GPU parity of the wave-pipelined encoder (zpq_pipe.hip: one wave per component, lane = block; levels 1-3)
+"""GPU parity of the wave-pipelined encoder (zpq_pipe.hip: one wave per component, lane = block; levels 1-5)
 against the CPU oracle and against the lane-per-component encoder (zpq_chain.hip, ZPQ_ENC_PIPE=0), through the C ABI."""
 import os
 import random
@@ -37,13 +37,14 @@ def encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=None, cap=None):
     return a, sa
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
 def test_both_encoders_agree_with_the_oracle(zpq, gpu_ctx, monkeypatch, level):
     """Ragged batch (empty, one byte, sizes around a dword and a nibble row), with and without the PP byte, more
     blocks than one workgroup holds."""
     rnd = random.Random(4000 + level)
     model = zpq.Model(level=level)
-    blocks = mixed_blocks(rnd, 75, [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 1000, 3000])
+    # (levels 4-5: the oracle clears 0.4 / 2 GiB of tables per block -- fewer blocks)
+    blocks = mixed_blocks(rnd, 75 if level <= 3 else 21, [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 1000, 3000])
     for flags, pp in ((zpq.FLAG_PP, True), (0, False)):
         coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=flags)
         assert (status == 0).all()
@@ -64,7 +65,7 @@ def small_table_header(level, bits):
     return bytes(h)
 
 
-@pytest.mark.parametrize("level,bits", [(1, 0), (1, 2), (2, 0), (2, 1), (2, 3), (3, 0), (3, 2)])
+@pytest.mark.parametrize("level,bits", [(1, 0), (1, 2), (2, 0), (2, 1), (2, 3), (3, 0), (3, 2), (4, 1), (5, 0), (5, 3)])
 def test_row_forwarding_under_heavy_aliasing(zpq, gpu_ctx, monkeypatch, level, bits):
     header = small_table_header(level, bits)
     model = zpq.Model(header=header)
@@ -80,31 +81,32 @@ def test_row_forwarding_under_heavy_aliasing(zpq, gpu_ctx, monkeypatch, level, b
     assert (status == 0).all() and dec == blocks
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
 def test_rounds_and_partial_workgroups(zpq, gpu_ctx, monkeypatch, level):
     """Fewer slots than blocks: every lane of the pipeline codes several blocks one after the other (tables, links and
     coder state must start clean), the last round and the last workgroup are partly idle."""
     model = zpq.Model(level=level)
     rnd = random.Random(99 + level)
-    blocks = mixed_blocks(rnd, 83, [0, 1, 300, 1200, 2048])
+    nslots = 19 if level <= 3 else 13
+    blocks = mixed_blocks(rnd, 83 if level <= 3 else 30, [0, 1, 300, 1200, 2048])
     want = O.encode_blocks(model.header, blocks, nthreads=4)
     monkeypatch.setenv("ZPQ_SPARSE_MODE", "never")
-    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 19 * model.state_bytes + 1000)
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, nslots * model.state_bytes + 1000)
     try:
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
-        assert gpu_ctx.last_kernel_name == "k_pipe<encode>" and gpu_ctx.last_slots == 19
+        assert gpu_ctx.last_kernel_name == "k_pipe<encode>" and gpu_ctx.last_slots == nslots
         assert (status == 0).all() and coded == want
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
 def test_line_store_through_the_pipeline(zpq, gpu_ctx, monkeypatch, level):
     """The compact line store under the wave-pipelined encoder: probing, claims, displaced lines (a small forced
     store), and the refusal of a block that needs more lines than promised."""
     model = zpq.Model(level=level)
     rnd = random.Random(31 + level)
-    blocks = mixed_blocks(rnd, 40, [0, 1, 17, 300, 1000, 1900])
+    blocks = mixed_blocks(rnd, 40 if level <= 3 else 20, [0, 1, 17, 300, 1000, 1900])
     want = O.encode_blocks(model.header, blocks, nthreads=4)
     monkeypatch.setenv("ZPQ_SPARSE_FORCE_LOG2", "13")
     coded, status = encode_both(zpq, gpu_ctx, monkeypatch, model, blocks)
@@ -135,7 +137,7 @@ def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
         assert coded == O.encode_blocks(model.header, blocks, nthreads=4)
 
 
-@pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024)])
+@pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024), (5, 512)])
 def test_full_size_batches(zpq, gpu_ctx, level, nb):
     """BASELINE.json's shapes (level 1: 4096 x 64 KiB, level 2: 8192 x 64 KiB): sampled blocks against the oracle,
     every block through the round trip."""

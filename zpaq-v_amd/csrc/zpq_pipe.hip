@@ -1,21 +1,22 @@
-// zpq_pipe.hip -- the ENCODER of the chain models (ICM + ISSEs: levels 1-3, levels.v:53-218) as a pipeline of WAVES.
+// zpq_pipe.hip -- the ENCODER of the chain models (ICM + ISSEs [+ MIX2]: levels 1-5, levels.v:53-375) as a pipeline of WAVES.
 //
 // Every context, coded bit and bit-history state of the encoder is a function of the input alone; only predictions
-// flow down the chain ICM -> ISSE -> ... -> coder, and every component trains on its OWN prediction
+// flow down the chain ICM -> ISSE -> ... [-> MIX2] -> coder, and every component trains on its OWN prediction
 // (predictor.v:701-709,776-791).  zpq_chain.hip maps a block to a group of lanes (lane = component) and, when
 // encoding, lets lane c run c bytes behind the ICM -- but all lanes of a wave still issue the union of the ICM's,
-// the ISSE's and the coder's instructions, and a wave that is alone on its SIMD issues one instruction every four
+// the ISSE's and the coder's instructions, and a wave that is alone on its SIMD issues one instruction every five
 // cycles: ~190 instructions = ~800 cycles per coded bit.
 //
 // Here the roles are separated by WAVE, and a lane is a block:
 //   * wave c < NCH owns component c of every block of the workgroup (its bit-history rows in HBM, its counters /
-//     weights in LDS -- the layout of zpq_chain_cfg.h), wave NCH is the arithmetic coder (encoder.v:48-139);
+//     weights in LDS -- the layout of zpq_chain_cfg.h), a MIX2 (levels 4-5) has the next wave, the last wave is the
+//     arithmetic coder (encoder.v:48-139);
 //   * in iteration `it` wave c works on byte it - c of every block; it takes its predecessor's eight predictions
 //     of that byte from LDS (16 bytes per block and link, double-buffered) and leaves its own there; the last
-//     component leaves squash(p), which is what the coder needs;
+//     stage leaves squash(p) and the bit, which is what the coder needs;
 //   * one s_barrier per byte keeps the waves in step (with an LDS-only wait in front of it: a full fence would
 //     also wait for the row prefetch every byte).
-// Each wave then issues only its own role's instructions (~50-80 per bit), four waves on four SIMDs side by side.
+// Each wave then issues only its own role's instructions (~50-135 per bit) on the CU's four SIMDs side by side.
 // Coded bytes are identical to zpq_chain.hip's, zpq_generic.hip's and the CPU oracle's.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -32,6 +33,7 @@ namespace zpqp {
 using namespace zpqc;
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+__device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
 __device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
 __device__ __forceinline__ i32 clamp512k(i32 x) { return min(max(x, -262144), 262143); }
 __device__ __forceinline__ uint32_t mul_shr16(uint32_t range, uint32_t p16)   // see zpq_chain.hip
@@ -129,7 +131,9 @@ struct Row {
 };
 
 // ------------------------------------------------------------------ a component stage
-template <int NCH, bool SP, bool HIO, bool IS_ICM, bool IS_LAST>
+// IS_LAST: the component the coder follows (its link carries squash(p) and the bit).  FWD_PIN: the last ISSE of a chain
+// that a MIX2 follows: it hands its INPUT on as well (the MIX2 mixes p[n-3] and p[n-2], levels.v:199-218,290-375).
+template <int NCH, bool SP, bool HIO, bool IS_ICM, bool IS_LAST, bool FWD_PIN>
 __device__ __forceinline__ void comp_loop(const StageArgs &S)
 {
     const DBatch &B = *S.B;
@@ -161,6 +165,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
     u8 *const t8 = S.my + cfg.lds_off8[ci];
     const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(ci > 0 ? ci - 1 : 0) * 2 * S.bpw + S.lane;
     uint4 *const link_out = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)ci * 2 * S.bpw + S.lane;
+    uint4 *const link_pin = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)(NCH + 1) * 2 * S.bpw + S.lane;   // (FWD_PIN)
     const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
     const u32 total = S.total;
     // Dense tables: a nibble's rows are requested a whole BYTE (two nibbles) before they are used -- every context of
@@ -459,6 +464,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
             bitstep(I3{}, I1{});
             hctx = hnext;
             link_out[(it & 1u) * S.bpw] = make_uint4(po0, po1, po2, po3);
+            if (FWD_PIN) link_pin[(it & 1u) * S.bpw] = make_uint4(pi0, pi1, pi2, pi3);
         }
         lds_barrier();
     }
@@ -467,6 +473,88 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
     // (the last nibbles' rows are not written back: the slot is re-initialised for the next block)
     if (S.lane < S.bpw) reinterpret_cast<i32 *>(lds + S.L.stat_off)[ci * S.bpw + S.lane] = status;
 #undef ZPP_LOAD_ROWS
+}
+
+// ------------------------------------------------------------------ the MIX2 stage (levels 4-5; predictor.v:587-592,776-791)
+// Component NCH mixes p[NCH-2] and p[NCH-1] with a 16-bit weight selected by (h + c8) -- with mask 255 the eight weights
+// of a byte are eight DISTINCT entries, known when the byte begins: they are loaded there (after the previous byte's
+// trained weights are stored: an entry may recur), trained in registers, stored when the next byte begins.  The wait
+// for the loads is this wave's own; its SIMD is shared with component waves that keep issuing.
+template <int NCH, bool HIO>
+__device__ __forceinline__ void mix_loop(const StageArgs &S)
+{
+    const DBatch &B = *S.B;
+    const DModel &M = *B.model;
+    u8 *const lds = S.lds;
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
+    const DComp &C = M.comp[NCH];
+    const i32 mix_rate = C.rate;
+    const u32 cmask = (u32)(C.c - 1);
+    u16 *const a16 = reinterpret_cast<u16 *>(S.slot + C.a16_off);
+    const uint4 *const link_k = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NCH - 1) * 2 * S.bpw + S.lane;
+    const uint4 *const link_j = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NCH + 1) * 2 * S.bpw + S.lane;
+    uint4 *const link_out = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)NCH * 2 * S.bpw + S.lane;
+    const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
+    const u32 total = S.total;
+    InWin W;
+    if (S.active) W.open(S.src, S.nin, B.in_off);
+    u32 prev = 0, hctx = 0, mh_prev = 0, mch_prev = 0;
+    u32 mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 it = 0;
+    for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+    const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
+    for (; it < it_end; it++) {
+        const u32 bi = it - (u32)NCH;
+        if (S.active && bi < total) {
+            const u32 pos = pp ? (bi ? bi - 1u : 0u) : bi;
+            const u32 cb = W.byte(pos);
+            const u32 ch = (pp && bi == 0) ? 0u : cb;
+            const uint4 vk = link_k[((it - 1u) & 1u) * S.bpw], vj = link_j[((it - 1u) & 1u) * S.bpw];
+            if (bi != 0) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) a16[(mh_prev + ((1u << t) | (mch_prev >> (8 - t)))) & cmask] = (u16)mw[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) mw[t] = a16[(hctx + ((1u << t) | (ch >> (8 - t)))) & cmask];
+            mh_prev = hctx;
+            mch_prev = ch;
+            u32 hnext;
+            {   // H[NCH] = hash^(NCH+1)(byte, previous byte)
+                u32 a = ch;
+                for (int k = 0; k <= NCH; k++) a = (a + prev + 512u) * 773u;
+                hnext = a;
+                prev = ch;
+            }
+            u32 po0 = 0, po1 = 0, po2 = 0, po3 = 0;
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const u32 yk = (ch >> (7 - kb)) & 1u;
+                const u32 wk = (kb >> 1) == 0 ? vk.x : ((kb >> 1) == 1 ? vk.y : ((kb >> 1) == 2 ? vk.z : vk.w));
+                const u32 wj = (kb >> 1) == 0 ? vj.x : ((kb >> 1) == 1 ? vj.y : ((kb >> 1) == 2 ? vj.z : vj.w));
+                const i32 pk = (i32)(int16_t)(wk >> ((kb & 1) * 16)), pj = (i32)(int16_t)(wj >> ((kb & 1) * 16));
+                const i32 w = (i32)mw[kb];
+                const i32 p = clamp2k(wadd(wmul(w, pj), wmul(65536 - w, pk)) >> 16);
+                const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+                const i32 err = (yk ? 32767 : 0) - sq;
+                const i32 em = wmul(err, mix_rate) >> 5;
+                i32 wn = wadd(w, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                wn = min(max(wn, 0), 65535);
+                mw[kb] = (u32)wn;
+                const u32 ov = (((u32)sq | (yk << 15)) & 0xFFFFu) << ((kb & 1) * 16);
+                if ((kb >> 1) == 0) po0 = (kb & 1) ? (po0 | ov) : ov;
+                else if ((kb >> 1) == 1) po1 = (kb & 1) ? (po1 | ov) : ov;
+                else if ((kb >> 1) == 2) po2 = (kb & 1) ? (po2 | ov) : ov;
+                else po3 = (kb & 1) ? (po3 | ov) : ov;
+            }
+            hctx = hnext;
+            link_out[(it & 1u) * S.bpw] = make_uint4(po0, po1, po2, po3);
+        }
+        lds_barrier();
+    }
+    if (HIO && phase == 0 && B.gate_flag) (void)gate_wait(B.gate_flag);
+    }   // phase
+    // (the last byte's weights are not written back: the slot is re-initialised for the next block)
+    if (S.lane < S.bpw) reinterpret_cast<i32 *>(lds + S.L.stat_off)[NCH * S.bpw + S.lane] = ZPQ_OK;
 }
 
 // ------------------------------------------------------------------ the coder stage (encoder.v:48-139)
@@ -489,17 +577,18 @@ struct Coder {
     }
 };
 
-template <int NCH, bool HIO>
+// NST = stages in front of the coder (= its distance in bytes from the ICM); their last one's link is its input
+template <int NST, bool HIO>
 __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
 {
     u8 *const lds = S.lds;
-    const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NCH - 1) * 2 * S.bpw + S.lane;
+    const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NST - 1) * 2 * S.bpw + S.lane;
     const u32 total = S.total;
     u32 it = 0;
     for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
     const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
     for (; it < it_end; it++) {
-        const u32 bi = it - (u32)NCH;
+        const u32 bi = it - (u32)NST;
 #ifdef ZPP_DEBUG_NO_CODER   // timing experiment only
         if (false) {
 #else
@@ -530,8 +619,9 @@ __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
     }   // phase (the coder reads no input: nothing to wait for)
 }
 
-template <int NCH, bool SP, bool HIO>
-__global__ void __launch_bounds__(64 * (NCH + 1)) k_pipe(const DBatch B, const Cfg cfg, const PipeLds L)
+// NCH = chain length (ICM + ISSEs), MIXT = a MIX2 follows it (levels 4-5); waves: NCH [+ 1] + the coder
+template <int NCH, bool MIXT, bool SP, bool HIO>
+__global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBatch B, const Cfg cfg, const PipeLds L)
 {
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -590,6 +680,15 @@ __global__ void __launch_bounds__(64 * (NCH + 1)) k_pipe(const DBatch B, const C
                     (blk_lds + cfg.lds_off8[c])[i] = (u8)((i32)a1 >> 12);
                 }
             }
+            if (MIXT) {                                                 // a16[] = 32768 (predictor.v:396)
+                __syncthreads();                                        // (behind the zero-fill above, which other waves did)
+                const DComp &cm2 = M.comp[NCH];
+                const u32 words = (cm2.a16_len + 1) / 2;
+                for (int b = 0; b < nact; b++) {
+                    u32 *w = reinterpret_cast<u32 *>(B.slots + (u64)(wg_slot0 + b) * M.slot_bytes + cm2.a16_off);
+                    for (u32 i = tid; i < words; i += nthr) w[i] = 0x80008000u;
+                }
+            }
             if (tid == 0) *misc = 0u;
         }
         __syncthreads();
@@ -604,25 +703,27 @@ __global__ void __launch_bounds__(64 * (NCH + 1)) k_pipe(const DBatch B, const C
         S.total = active ? S.nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u) : 0u;
         if (wave == 0) atomicMax(misc, S.total);
         __syncthreads();
-        S.iters = *misc + (u32)NCH;
+        constexpr int NST = NCH + (MIXT ? 1 : 0);                       // stages in front of the coder
+        S.iters = *misc + (u32)NST;
         // (the ICM is the stage furthest ahead: in iteration `it` it is at input byte <= it and holds <= 12 bytes more)
         S.split = (HIO && B.gate_flag) ? (B.gate_pos > 64u ? B.gate_pos - 64u : 0u) : S.iters;
 
         Coder X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
-        if (wave == 0) comp_loop<NCH, SP, HIO, true, false>(S);
-        else if (wave < NCH - 1) comp_loop<NCH, SP, HIO, false, false>(S);
-        else if (wave == NCH - 1) comp_loop<NCH, SP, HIO, false, true>(S);
-        else coder_loop<NCH, HIO>(S, X);
+        if (wave == 0) comp_loop<NCH, SP, HIO, true, false, false>(S);
+        else if (wave < NCH - 1) comp_loop<NCH, SP, HIO, false, false, false>(S);
+        else if (wave == NCH - 1) comp_loop<NCH, SP, HIO, false, !MIXT, MIXT>(S);
+        else if (MIXT && wave == NCH) mix_loop<NCH, HIO>(S);
+        else coder_loop<NST, HIO>(S, X);
         __syncthreads();
-        if (wave == NCH && active) {
+        if (wave == NST && active) {
             // ---- segment end: compress(-1) + flush (encoder.v:101-105,130-139)
             X.high = X.low;                                           // encode(1, 0): mid = low, high = mid
             X.shift_out();
             for (int sft = 24; sft >= 0; sft -= 8) X.put(X.high >> sft);
             const i32 *stat = reinterpret_cast<const i32 *>(lds + L.stat_off);
             i32 st = ZPQ_OK;
-            for (int c = 0; c < NCH; c++) { const i32 sc = stat[c * bpw + lane]; st = st ? st : sc; }
+            for (int c = 0; c < NST; c++) { const i32 sc = stat[c * bpw + lane]; st = st ? st : sc; }
             if (X.opos > X.cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
             B.out_len[blk] = X.opos;
             B.status[blk] = st;
@@ -639,16 +740,17 @@ using zpqc::Cfg;
 static bool pipe_layout(const Cfg &cfg, int bpw, zpqp::PipeLds *L, size_t *lds_bytes)
 {
     const int nch = cfg.nch_spec;
+    const int nlinks = nch + (cfg.has_mix2 ? 2 : 0);         // + the MIX2's own, + the last ISSE's input handed on to it
     size_t off = (size_t)zpqc::LDS_STATE + (size_t)bpw * cfg.lds_per_block;
     off = (off + 15) & ~(size_t)15;
-    L->link_off = (int32_t)off; off += (size_t)nch * 2 * bpw * 16;
-    L->stat_off = (int32_t)off; off += (size_t)nch * bpw * 4;
+    L->link_off = (int32_t)off; off += (size_t)nlinks * 2 * bpw * 16;
+    L->stat_off = (int32_t)off; off += (size_t)(nch + 1) * bpw * 4;
     L->misc_off = (int32_t)off; off += 16;
     *lds_bytes = off;
     return off <= 160 * 1024;
 }
 
-// The wave-pipelined encoder exists for the dense and line-store chains of levels 1-3.  ZPQ_ENC_PIPE=0 keeps the
+// The wave-pipelined encoder exists for the dense and line-store chains of levels 1-5.  ZPQ_ENC_PIPE=0 keeps the
 // lane-per-component encoder (tests compare the two).
 // (a batch of fewer than 12 resident blocks stays with the lane-per-component encoder: see zpq_launch_pipe)
 extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots)
@@ -658,7 +760,7 @@ extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots)
     if (ev && atoi(ev) == 0) return 0;
     Cfg cfg;
     if (!zpq_chain_build_cfg(M, &cfg)) return 0;
-    if (cfg.has_mix2 || !(cfg.nch_spec == 2 || cfg.nch_spec == 3 || cfg.nch_spec == 5)) return 0;
+    if (cfg.has_mix2 ? !(cfg.nch_spec == 6 || cfg.nch_spec == 8) : !(cfg.nch_spec == 2 || cfg.nch_spec == 3 || cfg.nch_spec == 5)) return 0;
     if (blocks_per_wg < 1 || blocks_per_wg > 64 || blocks_per_wg > cfg.blocks_per_wg) return 0;
     zpqp::PipeLds L;
     size_t lds = 0;
@@ -692,15 +794,18 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     // would then share SIMDs while other CUs idle (measured: 1024 blocks 254 ms instead of 114).  Asking for more than
     // half of the LDS keeps it at one workgroup per CU, one wave per SIMD.
     if (lds < 81 * 1024) lds = 81 * 1024;
-#define ZPP_LAUNCH(N, SPv, HIOv)                                                                                     \
+#define ZPP_LAUNCH(N, MX, SPv, HIOv)                                                                                 \
     do {                                                                                                             \
-        (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, SPv, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((zpqp::k_pipe<N, SPv, HIOv>), dim3(nwg), dim3(64 * ((N) + 1)), lds, stream, *B, cfg, L);  \
+        (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, MX, SPv, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqp::k_pipe<N, MX, SPv, HIOv>), dim3(nwg), dim3(64 * ((N) + ((MX) ? 2 : 1))), lds, stream, *B, cfg, L); \
     } while (0)
+    if (hio && !(cfg.nch_spec == 2 || cfg.nch_spec == 3)) return ZPQ_E_INTERNAL;
     switch (cfg.nch_spec) {
-    case 2: if (cfg.sparse) ZPP_LAUNCH(2, true, false); else if (hio) ZPP_LAUNCH(2, false, true); else ZPP_LAUNCH(2, false, false); break;
-    case 3: if (cfg.sparse) ZPP_LAUNCH(3, true, false); else if (hio) ZPP_LAUNCH(3, false, true); else ZPP_LAUNCH(3, false, false); break;
-    case 5: if (hio) return ZPQ_E_INTERNAL; if (cfg.sparse) ZPP_LAUNCH(5, true, false); else ZPP_LAUNCH(5, false, false); break;
+    case 2: if (cfg.sparse) ZPP_LAUNCH(2, false, true, false); else if (hio) ZPP_LAUNCH(2, false, false, true); else ZPP_LAUNCH(2, false, false, false); break;
+    case 3: if (cfg.sparse) ZPP_LAUNCH(3, false, true, false); else if (hio) ZPP_LAUNCH(3, false, false, true); else ZPP_LAUNCH(3, false, false, false); break;
+    case 5: if (cfg.sparse) ZPP_LAUNCH(5, false, true, false); else ZPP_LAUNCH(5, false, false, false); break;
+    case 6: if (cfg.sparse) ZPP_LAUNCH(6, true, true, false); else ZPP_LAUNCH(6, true, false, false); break;       /* level 4 */
+    case 8: if (cfg.sparse) ZPP_LAUNCH(8, true, true, false); else ZPP_LAUNCH(8, true, false, false); break;       /* level 5 */
     default: return ZPQ_E_INTERNAL;
     }
 #undef ZPP_LAUNCH
