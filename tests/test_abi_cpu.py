@@ -84,3 +84,33 @@ def test_no_gpu_means_loud_failure_not_fallback(zpq):
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in src and "zpaq_oracle" not in src and "zo_" not in src, f
+
+
+def test_encoder_choice_is_host_logic(zpq, monkeypatch):
+    """Which encoder a chain model's batch gets is decided on the host (no GPU needed): the wave-pipelined one
+    (zpq_pipe.hip) for the shipped levels' shapes from 12 resident blocks on, within the LDS capacity the chain layout
+    allows; the lane-per-component one otherwise (zpq_pipe_applies, internal; a zpq_model starts with its DModel)."""
+    L = zpq.lib()
+    L.zpq_pipe_applies.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.zpq_pipe_applies.restype = C.c_int
+    L.zpq_chain_blocks_per_wg.argtypes = [C.c_void_p]
+    L.zpq_chain_blocks_per_wg.restype = C.c_int
+    monkeypatch.delenv("ZPQ_ENC_PIPE", raising=False)
+    for level, cap in ((1, 32), (2, 32), (3, 16), (4, 16), (5, 12)):
+        m = zpq.Model(level=level)
+        assert L.zpq_chain_blocks_per_wg(m.h) == cap
+        assert L.zpq_pipe_applies(m.h, cap, 11) == 0            # a wave must not live on a handful of lanes
+        assert L.zpq_pipe_applies(m.h, cap, 12) == 1
+        assert L.zpq_pipe_applies(m.h, cap, 8192) == 1
+        assert L.zpq_pipe_applies(m.h, cap + 1, 8192) == 0      # more blocks than the workgroup's LDS holds
+        monkeypatch.setenv("ZPQ_ENC_PIPE", "0")
+        assert L.zpq_pipe_applies(m.h, cap, 8192) == 0
+        monkeypatch.delenv("ZPQ_ENC_PIPE")
+    # a chain with another program goes through the runtime-loop kernel; a non-chain model has no chain layout at all
+    hdr = bytes([3, 8, 0, 0, 2, 3, 16, 8, 16, 0, 0, 104, 17, 95, 0, 59, 135, 7, 112, 25, 60, 59, 112, 56, 0])
+    m = zpq.Model(header=hdr)
+    assert m.has_fast_path and L.zpq_pipe_applies(m.h, 8, 100) == 0
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from inputs import C4B
+    m = zpq.Model(header=C4B)
+    assert not m.has_fast_path and L.zpq_pipe_applies(m.h, 8, 100) == 0
