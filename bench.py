@@ -9,6 +9,10 @@ resident in HBM).  value = uncompressed MB / (t_comp + t_decomp), whole job.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT a launcher and with --gpus N > 1, it starts the N ranks itself (fresh child processes through
+torch.distributed.run, before anything here has touched a GPU), relays rank 0's JSON line and exits with the
+launcher's code.  Inside a rank --gpus must equal WORLD_SIZE, or the run stops.
+
 One rank per GPU; block b of the global batch goes to rank b mod N (static
 round-robin, no data-path collective); timing is barrier + synchronize on both
 sides, MAX over ranks; rank 0 prints ONE JSON line.
@@ -21,7 +25,7 @@ line gains:
   secondary        C2 (level 1, 4096 blocks), levels 3-4, C4a (level 5 at its
                    resident capacity) and C4b (all nine component types), each
                    with its own roofline
-  cpu_baseline     the C oracle on this host at nproc (<= 16) threads and at 1 thread
+  cpu_baseline     the C oracle on this host at nproc threads (value), at 16 threads and at 1 thread
 """
 import argparse
 import hashlib
@@ -52,23 +56,22 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(level, size, per_thread_blocks, one_thread_blocks):
+def cpu_baseline(level, size, host, per_thread_blocks, one_thread_blocks):
     """The C oracle (a restatement of the V CPU path -- V itself cannot be built
     here) timed on this host: compress+decompress of a bounded sample of the same
-    synthetic blocks, blocks divided statically over `cores` pthreads; then the
-    same at one thread."""
+    synthetic blocks (`host`: the headline batch), blocks divided statically over
+    `cores` pthreads: at every hardware thread this process may use (SURVEY.md 8(d):
+    nproc), at 16 threads and at one thread."""
     import oracle_lib as O
-    import workload as W
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
     hdr = O.level_header(level)
 
     def timed(nb, nthreads):
-        arr = W.make_blocks_fast(nb, size)
-        blocks = [arr[i].tobytes() for i in range(nb)]
+        nb = max(1, min(nb, len(host)))
+        blocks = [host[i].tobytes() for i in range(nb)]
         t0 = time.time()
         coded = O.encode_blocks(hdr, blocks, nthreads=nthreads, slack=size + size // 8 + 1024)
         t1 = time.time()
@@ -76,22 +79,24 @@ def cpu_baseline(level, size, per_thread_blocks, one_thread_blocks):
         t2 = time.time()
         assert dec == [b"\0" + b for b in blocks]
         B = nb * size
-        return B / (t2 - t0) / 1e6, B / (t1 - t0) / 1e6, B / (t2 - t1) / 1e6, t2 - t0
+        return {"value": round(B / (t2 - t0) / 1e6, 3), "comp_MBps": round(B / (t1 - t0) / 1e6, 3),
+                "decomp_MBps": round(B / (t2 - t1) / 1e6, 3), "cores": nthreads, "blocks": nb, "seconds": round(t2 - t0, 2)}
 
-    nb = per_thread_blocks * cores
-    v, vc, vd, secs = timed(nb, cores)
-    v1, vc1, vd1, secs1 = timed(one_thread_blocks, 1)
+    # one thread codes a 64 KiB block both ways in ~30 ms: 32 blocks per thread keep every leg at a few seconds
+    full = timed(per_thread_blocks * avail, avail)
+    t16 = timed(per_thread_blocks * 4 * min(avail, 16), min(avail, 16))
+    one = timed(one_thread_blocks, 1)
     return {
-        "value": round(v, 3), "unit": "MB/s", "cores": cores, "kind": "port",
-        "comp_MBps": round(vc, 3), "decomp_MBps": round(vd, 3), "seconds": round(secs, 2),
-        "one_thread": {"value": round(v1, 3), "comp_MBps": round(vc1, 3), "decomp_MBps": round(vd1, 3),
-                       "blocks": one_thread_blocks, "seconds": round(secs1, 2)},
+        "value": full["value"], "unit": "MB/s", "cores": avail, "kind": "port",
+        "comp_MBps": full["comp_MBps"], "decomp_MBps": full["decomp_MBps"], "seconds": full["seconds"],
+        "blocks": full["blocks"],
+        "sixteen_threads": t16, "one_thread": one,
         "nproc": os.cpu_count(), "nproc_available": avail, "cpu_model": cpu_model_string(),
-        "sample": "%d synthetic 64 KiB blocks (same generator, classes b mod 4), level %d, C oracle "
-                  "compress+decompress, %d pthreads (blocks divided statically), per-block table alloc+zero-fill "
-                  "included; one_thread = the first %d of those blocks on 1 thread.  A real V build adds bounds "
-                  "checks and interface dispatch per byte, so it would be slower than this port." % (
-                      nb, level, cores, one_thread_blocks),
+        "sample": "the first %d blocks of the headline batch (64 KiB, classes b mod 4), level %d, C oracle "
+                  "compress+decompress on %d pthreads = every hardware thread this process may run on (blocks divided "
+                  "statically; per-block table alloc+zero-fill included); sixteen_threads / one_thread = the first %d / %d "
+                  "of those blocks on 16 / 1 threads.  A real V build adds bounds checks and interface dispatch per byte, "
+                  "so it would be slower than this port." % (full["blocks"], level, avail, t16["blocks"], one["blocks"]),
     }
 
 
@@ -184,13 +189,27 @@ def main():
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip per_class / value_incl_pcie / secondary (N=1 extras)")
-    ap.add_argument("--cpu-blocks-per-thread", type=int, default=128)
+    ap.add_argument("--cpu-blocks-per-thread", type=int, default=32)
     ap.add_argument("--cpu-one-thread-blocks", type=int, default=48)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--state-budget-gib", type=float, default=0.0, help="cap the per-ctx state pool (rehearsals sharing one GPU)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain invocation: be the launcher.  Nothing in this process has touched a GPU (torch is not even imported), the
+        # ranks are fresh children, rank 0's JSON line goes to our stdout through the inherited descriptor.
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import numpy as np
     import torch
@@ -201,6 +220,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE is %d: the line would be mislabelled" % (a.gpus, world)
     if a.single_device:
         local_rank = 0
     if world > 1:
@@ -224,16 +244,14 @@ def main():
     mine = shard_indices(total_blocks, rank, world)          # block b -> rank b mod world
     assert len(mine) == nb
     # synthetic data of the global batch, this rank's round-robin share
+    # (SURVEY.md 8(d)'s generator, one block per global index b; host threads only to build the batch in seconds)
     host = np.empty((nb, size), dtype=np.uint8)
-    pool = {}
-    for i, b in enumerate(mine):
-        if b % 4 == 2:
-            key = 2 + 4 * ((b // 4) % 64)
-            if key not in pool:
-                pool[key] = W.make_block(key, size)
-            host[i] = pool[key]
-        else:
-            host[i] = W.make_block(b, size)
+
+    def _fill(i):
+        host[i] = W.make_block(mine[i], size)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(_fill, range(nb), chunksize=64))
     d_in = torch.from_numpy(host.reshape(-1)).to(dev)
     flags = z.FLAG_PP
     rb = ResidentBatch(z, ctx, torch, dev, nb, size)
@@ -266,6 +284,15 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
     all_ok = stats[1].item() == world
+    # which physical GPU each rank ran on (so that a reader of the N-GPU line can see N distinct devices)
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "device": local_rank, "name": props.name,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+    devices = [me]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
 
     res = None
     if rank == 0:
@@ -286,8 +313,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": "level %d (%s), %d x %d B blocks per GPU%s, one segment per "
-                                   "block, classes b mod 4 = zeros/uniform/markov-text/periodic (text blocks drawn "
-                                   "from 64 distinct generated blocks)" % (
+                                   "block, classes b mod 4 = zeros/uniform/markov-text/periodic (SURVEY 8(d) generator, "
+                                   "block b of the global batch on rank b mod N)" % (
                                        a.level, LEVEL_NAMES.get(a.level, "?"), nb, size,
                                        " (C5's per-GPU share of 65536 blocks over 8 GPUs)" if nb == 8192 else ""),
                        "blocks_per_gpu": nb, "block_bytes": size, "level": a.level,
@@ -298,6 +325,7 @@ def main():
             "decomp_MBps": round(nb * size / (dec_ms * 1e-3) / 1e6, 1),
             "kernel_ms": {rb.enc_name: round(enc_ms, 3), rb.dec_name: round(dec_ms, 3)},
             "resident_blocks": ctx.last_slots,
+            "devices": devices,
             "roofline": roof,
         }
 
@@ -440,7 +468,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.level, size, a.cpu_blocks_per_thread, a.cpu_one_thread_blocks)
+            res["cpu_baseline"] = cpu_baseline(a.level, size, host, a.cpu_blocks_per_thread, a.cpu_one_thread_blocks)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

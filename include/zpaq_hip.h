@@ -83,6 +83,9 @@ int zpq_ctx_set_state_budget(zpq_ctx *, uint64_t bytes);
 int zpq_ctx_set_max_block_bytes(zpq_ctx *, uint64_t bytes);
 /* Resident blocks (state slots) the last batch call used; for reporting. */
 int zpq_ctx_last_slots(const zpq_ctx *);
+/* Capacity (64-byte lines per hash table) of the compact line store the last batch call's kernel ran with;
+ * 0 = dense tables.  For reporting and for tests that must know which instantiation they exercised. */
+unsigned zpq_ctx_last_line_store(const zpq_ctx *);
 /* How many blocks of this model a single launch keeps resident on this ctx (the smaller of what
  * the CUs' LDS/wave slots hold and what the state budget holds); a larger batch is worked off by
  * the resident groups in turn.  flags as for the batch calls (kernel choice).  < 0 = ZPQ_E_*. */

@@ -160,12 +160,15 @@ def test_slot_reuse_and_overflow(zpq, gpu_ctx):
     assert status[0] == -7 and int(out_len[0]) == len(O.Codec(C4B).encode(INPUTS["lcg4k"]))
 
 
-def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
+@pytest.mark.parametrize("nb", [256, 16384])
+def test_c4b_at_baseline_block_size(zpq, gpu_ctx, nb):
     """C4b (all nine component types) on 64 KiB blocks of all four classes through the lanes kernel:
-    round-trip properties on every block, byte parity with the oracle on a sample."""
+    round-trip properties on every block, byte parity with the oracle on a sample.  16 384 blocks = the shape
+    bench.py's `secondary` ships (k_rows at its resident capacity, four workgroups per CU)."""
     import torch
     import workload as W
-    nb, size = 256, 65536
+    torch.cuda.empty_cache()
+    size = 65536
     arr = W.make_blocks_fast(nb, size)
     model = zpq.Model(header=C4B)
     dev = torch.device("cuda:0")
@@ -178,9 +181,12 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
     d_out = torch.zeros(nb * cap, dtype=torch.uint8, device=dev)
     d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
     d_len, d_st, d_dlen, d_cons, d_code, d_first, d_dst = (torch.zeros(nb, **i32) for _ in range(7))
+    torch.cuda.synchronize()                             # order torch's fills before the ctx stream's kernels
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     assert gpu_ctx.last_kernel_name == "k_rows<encode>"
+    if nb == 16384:
+        assert gpu_ctx.last_slots == min(nb, gpu_ctx.resident_capacity(model)) >= 8192
     gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
                               in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
                               d_first.data_ptr(), d_dst.data_ptr())
@@ -188,7 +194,7 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx):
     assert bool((d_st == 0).all()) and bool((d_dst == 0).all()) and bool((d_dlen == size).all())
     assert bool(torch.equal(d_dec, d_in)) and bool(torch.equal(d_cons, d_len)) and bool((d_first == 0).all())
     out, lens = d_out.cpu().numpy(), d_len.cpu().numpy()
-    sample = [0, 1, 2, 3, 130, 255]
+    sample = [0, 1, 2, 3, 130, 255] + ([4097, 8190, 12291, 16380, 16383] if nb > 256 else [])
     want = O.encode_blocks(C4B, [arr[i].tobytes() for i in sample], nthreads=6, slack=cap)
     for i, w in zip(sample, want):
         assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i

@@ -47,3 +47,23 @@ def test_two_rank_rehearsal_matches_one_rank(gpu_ctx):
     assert r1["config"]["blocks_per_gpu"] == 512 and r2["config"]["blocks_per_gpu"] == 256
     assert r1["coded_bytes"] == r2["coded_bytes"] > 0          # same 512 global blocks, whoever coded them
     assert r2["scaling"] == "weak" and r2["value"] > 0
+
+
+def test_plain_invocation_starts_its_own_ranks(gpu_ctx):
+    """`python bench.py --gpus 2 ...` with no launcher on the command line (the shape of the driver's N = 1 command)
+    must BE a 2-rank run: it starts the ranks itself, labels the line n_gpus = 2 and lists one device entry per rank."""
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--state-budget-gib", "24"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "512"] + common,
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                          "--blocks", "256"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    r1, r2 = _json_line(one.stdout), _json_line(two.stdout)
+    assert r2["n_gpus"] == 2 and len(r2["devices"]) == 2
+    assert sorted(d["rank"] for d in r2["devices"]) == [0, 1]
+    assert len({d["pid"] for d in r2["devices"]}) == 2           # two processes really ran
+    assert r2["roundtrip_bit_exact"] and r1["coded_bytes"] == r2["coded_bytes"] > 0

@@ -137,11 +137,13 @@ def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
         assert coded == O.encode_blocks(model.header, blocks, nthreads=4)
 
 
-@pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024), (5, 512)])
+@pytest.mark.parametrize("level,nb", [(1, 4096), (2, 8192), (3, 1024), (5, 512), (3, 4096), (4, 4096), (5, 3072)])
 def test_full_size_batches(zpq, gpu_ctx, level, nb):
-    """BASELINE.json's shapes (level 1: 4096 x 64 KiB, level 2: 8192 x 64 KiB): sampled blocks against the oracle,
-    every block through the round trip."""
+    """BASELINE.json's shapes (level 1: 4096 x 64 KiB, level 2: 8192 x 64 KiB) and the shapes bench.py's `secondary`
+    ships (levels 3 and 4 at 4096 blocks, level 5 at 3072: the LINE-STORE instantiations at resident capacity -- the
+    1024 / 512-block cases run the dense ones): sampled blocks against the oracle, every block through the round trip."""
     import torch
+    torch.cuda.empty_cache()                             # (earlier tests' cached buffers count against the state budget)
     model = zpq.Model(level=level)
     size = 65536
     arr = W.make_blocks_fast(nb, size)
@@ -158,6 +160,12 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     gpu_ctx.sync()
     assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
+    if level >= 3 and nb >= 3072:
+        # what bench.py measures: every block resident at once, hash tables in the compact line store
+        # (resident blocks = what the LDS holds, 4096 / 3072, unless this process's other buffers leave less HBM)
+        assert gpu_ctx.last_line_store > 0 and gpu_ctx.last_slots == min(nb, gpu_ctx.resident_capacity(model)) >= 2048
+    elif level == 3:
+        assert gpu_ctx.last_line_store == 0
     assert bool((d_st == 0).all())
     lens = d_len.cpu().numpy()
     outc = d_out.cpu().numpy()
@@ -174,6 +182,8 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
                               in_off.data_ptr(), d_dlen.data_ptr(), aux[0].data_ptr(), aux[1].data_ptr(),
                               aux[2].data_ptr(), aux[3].data_ptr())
     gpu_ctx.sync()
+    if level >= 3 and nb >= 3072:
+        assert gpu_ctx.last_line_store > 0 and gpu_ctx.last_slots >= 2048
     assert bool((aux[3] == 0).all()) and bool(torch.equal(d_dec, d_in)) and bool((d_dlen == size).all())
 
 

@@ -66,3 +66,27 @@ def test_round_robin_two_ranks_matches_single_rank():
     assert got[0][2] == got[1][2] == float(sum(len(c) for c in single))
     assert shard_indices(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((shard_indices(11, r, 3) for r in range(3)), [])) == list(range(11))
+
+
+def test_bench_refuses_a_gpus_flag_that_is_not_the_world_size():
+    """bench.py --gpus N inside a launcher's rank must see WORLD_SIZE == N; a mislabelled line is worse than none
+    (`--gpus` used to be parsed and never read).  Fails before anything touches a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE is 1" in r.stderr, r.stderr[-1500:]
+
+
+def test_markov_generator_forms_agree():
+    """The vectorised order-1 Markov text generator (one prefix sum per block) equals SURVEY 8(d)'s symbol-by-symbol recurrence."""
+    import numpy as np
+    import workload as W
+    for b in (2, 6, 4094, 123458):
+        for size in (1, 5, 4096, 65536):
+            r = W._splitmix_stream((W.SEED0 + b) & W.MASK, size)
+            fav = ((r >> np.uint64(8)) & np.uint64(3)).astype(np.int64)
+            uni = ((r >> np.uint64(16)) & np.uint64(63)).astype(np.int64)
+            uf = (r & np.uint64(3)) != 0
+            assert np.array_equal(W._markov_text(uf, fav, uni), W._markov_text_loop(uf, fav, uni)), (b, size)

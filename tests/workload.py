@@ -18,6 +18,37 @@ def _splitmix_stream(seed, n):
     return z
 
 
+def _markov_text_loop(use_fav, fav, uni):
+    """The recurrence as SURVEY.md 8(d) states it, one symbol at a time (kept as the checker of the
+    vectorised form below: tests/test_sharding_gloo.py::test_markov_generator_forms_agree)."""
+    cur = 0
+    uf = use_fav.tolist(); fv = fav.tolist(); un = uni.tolist()
+    o = bytearray(len(uf))
+    for i in range(len(uf)):
+        cur = (cur * 7 + fv[i]) & 63 if uf[i] else un[i]
+        o[i] = 32 + cur
+    return np.frombuffer(bytes(o), dtype=np.uint8).copy()
+
+
+def _markov_text(use_fav, fav, uni):
+    """cur_i = (7 cur_{i-1} + fav_i) mod 64, or uni_i where use_fav_i is false.  7 is a unit mod 64
+    (7 * 55 = 1), so with a_i = 55^i cur_i the recurrence is a prefix sum a_i = a_{i-1} + 55^i fav_i
+    that restarts at every reset position: one cumsum for the whole block."""
+    n = len(fav)
+    idx = np.arange(n, dtype=np.int64)
+    pw = np.ones(16, dtype=np.int64); ipw = np.ones(16, dtype=np.int64)
+    for k in range(1, 16):
+        pw[k] = pw[k - 1] * 7 % 64
+        ipw[k] = ipw[k - 1] * 55 % 64
+    p7 = pw[idx & 15]; i7 = ipw[idx & 15]            # 7^16 = 1 mod 64
+    S = np.cumsum(np.where(use_fav, fav * i7, 0))
+    r = np.maximum.accumulate(np.where(use_fav, -1, idx))     # last reset position <= i (-1: none yet)
+    rr = np.maximum(r, 0)
+    base = np.where(r >= 0, uni[rr] * i7[rr] - S[rr], 0)
+    cur = (p7 * (base + S)) & 63
+    return (32 + cur).astype(np.uint8)
+
+
 def make_block(b, size=65536):
     cls = b % 4
     seed = (SEED0 + b) & MASK
@@ -32,22 +63,14 @@ def make_block(b, size=65536):
         fav = ((r >> np.uint64(8)) & np.uint64(3)).astype(np.int64)
         uni = ((r >> np.uint64(16)) & np.uint64(63)).astype(np.int64)
         use_fav = ((r & np.uint64(3)) != 0)
-        out = np.empty(size, dtype=np.uint8)
-        cur = 0
-        uf = use_fav.tolist(); fv = fav.tolist(); un = uni.tolist()
-        o = bytearray(size)
-        for i in range(size):
-            cur = (cur * 7 + fv[i]) & 63 if uf[i] else un[i]
-            o[i] = 32 + cur
-        return np.frombuffer(bytes(o), dtype=np.uint8).copy()
+        return _markov_text(use_fav, fav, uni)
     per = 16 + (b % 4080)
     base = (r[:per] & np.uint64(255)).astype(np.uint8)
     return np.tile(base, size // per + 1)[:size].copy()
 
 
 def make_blocks(nblocks, size=65536, start=0):
-    """Returns a (nblocks, size) uint8 array.  Class-2 blocks use a Python loop
-    (about 40 ms each); they are cached per process."""
+    """Returns a (nblocks, size) uint8 array: block start + i of SURVEY.md 8(d)'s generator."""
     out = np.empty((nblocks, size), dtype=np.uint8)
     for i in range(nblocks):
         out[i] = make_block(start + i, size)

@@ -53,6 +53,8 @@ def lib():
     L.zpq_ctx_set_state_budget.argtypes = [vp, u64]
     L.zpq_ctx_set_max_block_bytes.argtypes = [vp, u64]
     L.zpq_ctx_last_slots.argtypes = [vp]
+    L.zpq_ctx_last_line_store.argtypes = [vp]
+    L.zpq_ctx_last_line_store.restype = C.c_uint
     L.zpq_ctx_resident_capacity.argtypes = [vp, vp, u32]
     L.zpq_ctx_last_kernel_ms.argtypes = [vp]
     L.zpq_ctx_last_kernel_ms.restype = C.c_float
@@ -203,6 +205,11 @@ class Context:
     @property
     def last_slots(self):
         return lib().zpq_ctx_last_slots(self.h)
+
+    @property
+    def last_line_store(self):
+        """Lines per hash table of the compact line store the last launch ran with (0 = dense tables)."""
+        return lib().zpq_ctx_last_line_store(self.h)
 
     def resident_capacity(self, model, flags=FLAG_PP):
         """Blocks of `model` one launch keeps resident on this GPU (zpq_ctx_resident_capacity)."""

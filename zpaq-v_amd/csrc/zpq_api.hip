@@ -97,6 +97,7 @@ struct zpq_ctx {
     DevBuf slots;
     uint64_t budget = 0;
     int last_slots = 0;
+    uint32_t last_sp = 0;                  // line-store capacity the last launch ran with (0 = dense)
     const char *last_name = "";
     // staging for the host-pointer entry points
     DevBuf s_in, s_out, s_inoff, s_outoff, s_u32[4], s_status, s_misc;
@@ -267,6 +268,7 @@ extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
     return ZPQ_OK;
 }
 extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return c ? c->last_slots : 0; }
+extern "C" unsigned zpq_ctx_last_line_store(const zpq_ctx *c) { return c ? c->last_sp : 0u; }
 extern "C" const char *zpq_ctx_last_kernel_name(const zpq_ctx *c) { return c ? c->last_name : ""; }
 extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
 {
@@ -440,6 +442,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     }
     B.nslots = nslots;
     c->last_slots = nslots;
+    c->last_sp = P.sp;
 
     HIPCK(hipEventRecord(c->ev0, c->stream));
     if (want_chain && !a.own_slot) {
