@@ -1303,6 +1303,10 @@ extern "C" int zpq_chain_has_hio(const DModel *M)
 extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots);
 extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream);
 
+// zpq_dpipe.hip: the wave-split decoder of the dense chains without a MIX2
+extern "C" int zpq_dpipe_applies(const DModel *M, int blocks_per_wg, int nslots);
+extern "C" int zpq_launch_dpipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream);
+
 extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode, int nwg, int blocks_per_wg,
                                 hipStream_t stream, const char **name_out)
 {
@@ -1315,6 +1319,10 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (!decode && zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) {
         if (name_out) *name_out = "k_pipe<encode>";
         return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream);
+    }
+    if (decode && !B->prog_counter && zpq_dpipe_applies(hostM, blocks_per_wg, B->nslots)) {
+        if (name_out) *name_out = "k_dpipe<decode>";
+        return zpq_launch_dpipe(B, hostM, nwg, blocks_per_wg, stream);
     }
     cfg.blocks_per_wg = blocks_per_wg;
     cfg.lds_dummy = blocks_per_wg * cfg.lds_per_block;
