@@ -22,13 +22,12 @@ def decode_both(zpq, gpu_ctx, monkeypatch, model, coded, cap, flags=None):
     """Decode with both decoders; everything the ABI returns must agree (a refused block's bytes are unspecified)."""
     kw = {} if flags is None else {"flags": flags}
     assert len(coded) >= 12                      # (smaller batches stay with the lane-per-component decoder)
-    monkeypatch.delenv("ZPQ_DEC_PIPE", raising=False)
+    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")      # (opt-in: the lane-per-component decoder measured faster, DESIGN.md 4.5)
     a = gpu_ctx.decode_blocks(model, coded, cap=cap, **kw)
     assert gpu_ctx.last_kernel_name == "k_dpipe<decode>"
-    monkeypatch.setenv("ZPQ_DEC_PIPE", "0")
+    monkeypatch.delenv("ZPQ_DEC_PIPE", raising=False)
     b = gpu_ctx.decode_blocks(model, coded, cap=cap, **kw)
     assert gpu_ctx.last_kernel_name == "k_chain<decode>"
-    monkeypatch.delenv("ZPQ_DEC_PIPE", raising=False)
     assert list(a[1]) == list(b[1])
     for i in range(len(coded)):
         if a[1][i] == 0:
@@ -81,6 +80,7 @@ def test_rounds_and_partial_workgroups(zpq, gpu_ctx, monkeypatch, level):
     blocks = mixed_blocks(rnd, 83, [0, 1, 300, 1200, 2048])
     coded = O.encode_blocks(model.header, blocks, nthreads=4)
     monkeypatch.setenv("ZPQ_SPARSE_MODE", "never")
+    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")
     zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, nslots * model.state_bytes + 1000)
     try:
         dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=2100)
@@ -103,7 +103,8 @@ def test_output_overflow_and_garbage_input(zpq, gpu_ctx, monkeypatch):
     decode_both(zpq, gpu_ctx, monkeypatch, model, junk, 1500)
 
 
-def test_small_batches_stay_with_the_lane_per_component_decoder(zpq, gpu_ctx):
+def test_small_batches_stay_with_the_lane_per_component_decoder(zpq, gpu_ctx, monkeypatch):
+    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")
     model = zpq.Model(level=2)
     for n, name in ((1, "k_chain<decode>"), (11, "k_chain<decode>"), (12, "k_dpipe<decode>"), (37, "k_dpipe<decode>")):
         blocks = [bytes(W.make_block(b, 700 + 13 * b)) for b in range(n)]

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         const u32 cx_ = (hc_) + 16u * (c8v_);                                           \
         chk_ = (cx_ >> sizebits) & 255u;                                                \
         const u32 h0_ = (cx_ * 16u) & ht_mask;                                          \
-        u32 pox_ = h0_;                                                                 \
+        u32 pox_ = SWZ ? swz_addr(h0_) : h0_;                                           \
         if (SPARSE && sp_cap) {                                                         \
             key_ = (h0_ >> 6) + 1u;                                                     \
             si_ = __umulhi(key_ * 0x9E3779B1u, sp_cap);                                 \
@@ -430,6 +430,22 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         po_ = pox_;                                                                     \
         ZPQ_LOAD_ROWS(A_, B_, C_, pox_);                                                \
     } while (0)
+        // Two-hypothesis decode: inside this launch a table's 64-byte lines are TRANSPOSED -- line (h0 >> 6) & 3 of every
+        // 256-byte group moves to quarter (h0 >> 6) & 3 of the table, the groups keep their order inside a quarter (a
+        // bijection on lines; h0 ^ 16 and h0 ^ 32 stay inside the line; the layout lives and dies with the launch).  The
+        // contexts of a byte's second nibble are 16 * c8 apart (predictor.v:558-560), their lines 256 bytes apart: transposed,
+        // the lines of neighbouring c8 are NEIGHBOURS, so the two copies' requests for the two outcomes of the fourth bit fall
+        // into one 128-byte block half of the time (one request to the memory system instead of two; tools/micro/rowlat.hip).
+#ifdef ZPQ_NO_SWZ
+        constexpr bool SWZ = false;
+#else
+        constexpr bool SWZ = HYP;
+#endif
+        const u32 swz_q = hashed && C.ht_len >= 1024u ? (u32)(31 - __clz((int)C.ht_len)) - 8u : 0u;   // log2(quarter) - 6; 0 = table too small
+        auto swz_addr = [&](const u32 h0) -> u32 {
+            const u32 t = ((h0 & 0xC0u) << swz_q) | ((h0 >> 2) & ((64u << swz_q) - 64u)) | (h0 & 63u);
+            return swz_q ? t : h0;
+        };
         auto load_rows = [&](const u32 po) { ZPQ_LOAD_ROWS(nA, nB, nC, po); };
         auto prefetch_rows = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(nA, nB, nC, n_tags, n_po, n_chk, n_key, n_si, n_off, hc, c8v); };
         auto prefetch_alt = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(aA, aB, aC, a_tags, a_po, a_chk, a_key, a_si, a_off, hc, c8v); };
@@ -445,10 +461,23 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             return t;
         };
         bool row_mine = true;                              // this copy requested the rows of the nibble that really follows
-        auto take_prefetched = [&](const bool have_prev) {
+        // Two-hypothesis decode, a byte's SECOND nibble: its 16 possible contexts are hctx + 16 * (16..31) (predictor.v:558-560),
+        // i.e. -- in the transposed layout above -- 16 neighbouring lines.  So the request need not wait for the first nibble's
+        // third bit: when the SECOND bit is known each copy asks for the two lines of ITS outcome of the third bit (both outcomes
+        // of the fourth: neighbouring lines, half of the time one 128-byte block), two whole bit steps before they are needed --
+        // the HBM round trip (~2000 cycles under this load, tools/micro/rowlat.hip) then hides completely instead of by half.
+        // Four lines per table and byte instead of two, but four NEIGHBOURING ones: asking two steps early for four lines 256
+        // bytes apart was measured slower in round 2 (321 vs 267 ms).
+#ifdef ZPQ_NO_HYP4
+        constexpr bool HYP4 = false;
+#else
+        constexpr bool HYP4 = HYP && SWZ && NCH == 3;         // (level 1, one hashed table of 32 MiB beside a small one: measured 272 vs 269 ms)
+#endif
+        auto take_prefetched = [&](const bool have_prev, auto midc) {
+            constexpr bool MID = decltype(midc)::value;        // the rows of a byte's second nibble
             bool claim = false;
             u32 claim_si = 0;
-            if (TWO) {                                         // (selects, not a branch: both requests are waited for here anyway)
+            if (TWO || (HYP4 && MID)) {                        // (selects, not a branch: both requests are waited for here anyway)
                 auto sel4 = [](const bool c, const u32x4 a, const u32x4 b) -> u32x4 {
                     return u32x4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
                 };
@@ -966,7 +995,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 cur_s = bs >> 8;
                 cur_pst = icm_st(cur_v, cur_b);
             } else {
-                row_mine = mine;
+                if (HYP4 && bit == 4) sel_alt = y != 0;         // (the copy whose third bit was right holds both outcomes of this one)
+                else row_mine = mine;
                 if (bit == 0) {
                     const u32 xh = xchg(hn_spec);
                     hnext_dec = mine ? hn_spec : xh;
@@ -983,7 +1013,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             else { X.r3 = (X.slot & 4u) ? ins : X.r3; X.r2 = (X.slot & 4u) ? X.r2 : ins; }
             X.c8 = (X.c8 << 1) | (u32)y;
             X.slot = (K == 3) ? 1u : (X.slot * 2u + (u32)y);
-            if (K == 2) {
+            if (HYP4 && bit == 6) {
+                // two bits of the byte's first nibble are known: the second nibble's rows for this copy's outcome of the
+                // third bit, both outcomes of the fourth (see HYP4 above)
+                const u32 c8n = (X.c8 << 2) | ((u32)hyp << 1);
+                prefetch_alt(hctx, c8n | 1u);
+                prefetch_rows(hctx, c8n);
+            }
+            if (HYP4 && bit == 5) row_mine = mine;
+            if (K == 2 && !(HYP4 && bit == 5)) {
                 // Three bits of the nibble are known: this copy asks for the rows of the next nibble under ITS outcome of
                 // the fourth.  The request has the whole last bit step (~1000 cycles) to travel before it is needed;
                 // the HBM round trip measured here is ~1350 cycles.
@@ -1059,7 +1097,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 
             X.c8 = 1; X.slot = 1;
             u32 hnext = 0;
-            take_prefetched(bi != 0);                         // rows of this byte's first nibble
+            take_prefetched(bi != 0, std::false_type{});      // rows of this byte's first nibble
             if (DEC && pend_store) { dst[pend_pos] = (u8)pend_val; pend_store = false; }   // (see pend_store)
             if (!DEC && is_last) oq_flush();
             if (DEC && mixreg) mixw_arrive();
@@ -1073,7 +1111,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
             step(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
-            take_prefetched(true);
+            take_prefetched(true, std::true_type{});
             if (DEC && mixreg) mixw_arrive();
             if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();

@@ -44,6 +44,30 @@ __device__ __forceinline__ uint32_t mul_shr16(uint32_t range, uint32_t p16)   //
 }
 // LDS traffic of this wave done, then the workgroup barrier (no wait for global memory: row requests stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef ZPD_PROF
+// Timing build (tools/variant.sh): per wave of workgroup 0, cycles spent working and waiting per bit position.
+// prof[wave][kb][0] = cycles between leaving a barrier and reaching the next, [1] = cycles inside the barrier.
+__device__ unsigned long long zpd_prof[16][8][2];
+struct Prof {
+    unsigned long long t_rel, acc[8][2];
+    bool on;
+    __device__ void init(bool o) { on = o; for (int k = 0; k < 8; k++) { acc[k][0] = 0; acc[k][1] = 0; } t_rel = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void barrier(const int kb)
+    {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        lds_barrier();
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        acc[kb][0] += t0 - t_rel; acc[kb][1] += t1 - t0; t_rel = t1;
+    }
+    __device__ void flush(const int wave)
+    {
+        if (on && (threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) { zpd_prof[wave][k][0] += acc[k][0]; zpd_prof[wave][k][1] += acc[k][1]; }
+    }
+};
+#define ZPD_BARRIER(kb_) prof.barrier(kb_)
+#else
+#define ZPD_BARRIER(kb_) lds_barrier()
+#endif
 // the same register of the block's other hypothesis lane (lane ^ 1)
 __device__ __forceinline__ u32 xchg(const u32 v)
 {
@@ -107,15 +131,19 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
     const int bl = S.lane >> 1;                        // its block inside the workgroup
     const DComp &C = M.comp[ci];
     const u32 ht_mask = C.ht_len - 16u;
+    const bool swz = C.ht_len >= 512u;                 // (tables smaller than 512 bytes have no bit 8: tests)
     u8 *const tbase = S.slot + C.ht_off;
     const int sizebits = C.a + 2;
     u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
     u8 *const t8 = S.my + cfg.lds_off8[ci];
     const int bpw = S.bpw;
-    const uint2 *const cand_in = reinterpret_cast<const uint2 *>(lds + S.L.cand_off) + (bl < bpw ? bl : 0) * 2;
+    const uint4 *const cand_in4 = reinterpret_cast<const uint4 *>(lds + S.L.cand_off) + (bl < bpw ? bl : 0);
     uint2 *const cand_out = reinterpret_cast<uint2 *>(lds + S.L.cand_off) + ((size_t)ci * 2 * bpw + (bl < bpw ? bl : 0)) * 2 + h;
     const u32 *const ymail = reinterpret_cast<const u32 *>(lds + S.L.ymail_off) + (bl < bpw ? bl : 0);
 
+#ifdef ZPD_PROF
+    Prof prof; prof.init(blockIdx.x == 0);
+#endif
     i32 status = ZPQ_OK;
     const bool on = S.active;                          // this lane has a block this round: the others run along (their loads are
                                                        // harmless) but must not write -- their addresses alias block 0's
@@ -138,7 +166,12 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
         Req q;
         const u32 cx = hc + 16u * c8v;
         q.chk = (cx >> sizebits) & 255u;
-        q.po = (cx * 16u) & ht_mask;
+        const u32 h0 = (cx * 16u) & ht_mask;
+        // Inside this kernel a table's 64-byte lines live at their address with bits 6 and 8 exchanged (a bijection; the
+        // rows h0 ^ 16, h0 ^ 32 stay inside the line).  The two outcomes of a byte's FOURTH bit lead to contexts 16 apart
+        // (predictor.v:558-560), i.e. lines 256 bytes apart: exchanged, the lane pair asks for the two halves of one
+        // aligned 128-byte block -- one request to the memory system instead of two (tools/micro/rowlat.hip: -20 % latency).
+        q.po = swz ? ((h0 & ~0x140u) | ((h0 >> 2) & 0x40u) | ((h0 << 2) & 0x100u)) : h0;
         ZPD_LOAD_ROWS(q, q.po);
         return q;
     };
@@ -213,34 +246,59 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
         if (on) cand_out[(size_t)par * bpw * 2] = o;
     };
 
+    // The published entries of the components below this one, for the bit about to be predicted: both outcomes' halves,
+    // read right behind the barrier together with the decoded bit (a read whose address depends on the bit would be a
+    // second LDS round trip in series).
+    constexpr int NIN = NCH - 1;
+    uint4 cin[NIN > 0 ? NIN : 1];
+    auto load_cands = [&](const int par) {
+#pragma unroll
+        for (int j = 0; j < NIN; j++)
+            if (j < ci) cin[j] = cand_in4[(size_t)(j * 2 + par) * bpw];
+    };
+
     // One coded bit.  K = bit inside the nibble (selects at compile time which dword of the row holds the slot:
     // slot 1 | 2..3 | 4..7 | 8..15, predictor.v:817-823), NB = nibble of the byte.
+    // Program order = the order the waits come in: state and entry reads that depend on nothing newer than the last
+    // commit go out first, the chain and the squash read follow, everything is consumed behind them.
     auto cycle = [&](auto kc, auto nbc) {
         constexpr int K = decltype(kc)::value;
         constexpr int NB = decltype(nbc)::value;
         constexpr int kb = NB * 4 + K;                 // position in coding order 0..7
-        constexpr int par = kb & 1, ppar = par ^ 1;
+        constexpr int par = kb & 1;
         const u32 s = cur_s;
-        // ---- the prediction of this bit, up to this component (inputs: the entries published for it, the previous bit picks)
+        // ---- (1) reads that need only the committed state
+        const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);       // next state for y=0 | y=1 << 8
+        u32 sN = 0, rNv = 0;
+        i32 rNb = 0;
+        if (K < 3) {
+            u32 pair;
+            if (K == 0) pair = row.x >> 16;
+            else if (K == 1) pair = row.y >> ((slotn & 1u) * 16u);
+            else pair = ((slotn & 2u) ? row.w : row.z) >> ((slotn & 1u) * 16u);
+            sN = h ? ((pair >> 8) & 255u) : (pair & 255u);
+            rNv = t32[sN];
+            rNb = (i32)(int8_t)t8[sN];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (2) the prediction of this bit, up to this component
         i32 pin = 0, sq = 0;
         const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE: sext20
         const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
         if (!IS_ICM) {
-            // (the lane that assumed the right previous bit wrote half `yprev` of each entry)
-            const uint2 *const cin = cand_in + yprev;
-            pin = (i32)cin[(size_t)(0 * 2 + ppar) * bpw * 2].x;
+            pin = (i32)(yprev ? cin[0].z : cin[0].x);
 #pragma unroll
-            for (int j = 1; j < NCH; j++) {
+            for (int j = 1; j < NIN; j++) {
                 if (j < ci) {
-                    const uint2 cj = cin[(size_t)(j * 2 + ppar) * bpw * 2];
-                    pin = clamp2k((__mul24((i32)cj.x, pin) + (i32)cj.y) >> 16);
+                    const i32 a = (i32)(yprev ? cin[j].z : cin[j].x), b = (i32)(yprev ? cin[j].w : cin[j].y);
+                    pin = clamp2k((__mul24(a, pin) + b) >> 16);
                 }
             }
             const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);     // predictor.v:615-631
             sq = s_squash[min(max(p + 2047, 0), 4093)];
         }
-        // ---- this lane's outcome of the bit: h
-        const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);       // next state for y=0 | y=1 << 8
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (3) this lane's outcome of the bit: h
         u32 nv;
         i32 nb;
         if (IS_ICM) {
@@ -257,14 +315,7 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
             nv = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
             nb = nw1 >> 12;
         }
-        u32 sN;
-        if (K < 3) {
-            u32 pair;
-            if (K == 0) pair = row.x >> 16;
-            else if (K == 1) pair = row.y >> ((slotn & 1u) * 16u);
-            else pair = ((slotn & 2u) ? row.w : row.z) >> ((slotn & 1u) * 16u);
-            sN = h ? ((pair >> 8) & 255u) : (pair & 255u);
-        } else {
+        if (K == 3) {
             // the nibble ends with this bit: resolve the next nibble's row for this lane's outcome (requested when the
             // third bit became known).  The row that is ending counts as updated with this lane's outcome.
             Row rh = row;
@@ -275,22 +326,30 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
             rh.w = (slotn & 4u) ? ins : rh.w; rh.z = (slotn & 4u) ? rh.z : ins;
             nrow = consume(req, rh);
             sN = (nrow.x >> 8) & 255u;
+            rNv = t32[sN];
+            rNb = (i32)(int8_t)t8[sN];
         }
-        const u32 rNv = t32[sN];
-        const i32 rNb = (i32)(int8_t)t8[sN];
         const bool same = sN == s;
         const u32 nxt_v = same ? nv : rNv;
         const u32 nxt_bs = ((u32)(same ? nb : rNb) & 255u) | (sN << 8);
         publish(par, nxt_v, (i32)(int8_t)(nxt_bs & 255u));
-        lds_barrier();
-        // ---- the bit
+        // what the neighbour lane holds for ITS outcome: fetched before the bit is known, picked after
+        const u32 xv = xchg(nxt_v), xb = xchg(nxt_bs);
+        u32 x0 = 0, x1 = 0, x2 = 0, x3 = 0, xo = 0, xh = 0;
+        if (K == 3) {
+            x0 = xchg(nrow.x); x1 = xchg(nrow.y); x2 = xchg(nrow.z); x3 = xchg(nrow.w); xo = xchg(nrow.off);
+            if (NB == 1) xh = xchg(hn_spec);
+        }
+        ZPD_BARRIER(kb);
+        // ---- (4) the bit, and the entries the next bit is predicted from
         const u32 ym = ymail[(size_t)par * bpw];
+        load_cands(par);
+        __builtin_amdgcn_sched_barrier(0);
         const u32 y = ym & 1u;
         alive = alive && (ym & 2u) == 0u;
         const bool mine = y == h;
         if (mine && on) { t32[s] = nv; t8[s] = (u8)nb; }    // one lane trains the block's table entry
         {
-            const u32 xv = xchg(nxt_v), xb = xchg(nxt_bs);
             cur_v = mine ? nxt_v : xv;
             const u32 bs = mine ? nxt_bs : xb;
             cur_b = (i32)(int8_t)(bs & 255u);
@@ -312,12 +371,10 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
 #ifndef ZPD_DEBUG_NO_ROWS
             if (alive && h == 0u && row.off != 0xFFFFFFFFu) *reinterpret_cast<u32x4 *>(tbase + row.off) = u32x4{row.x, row.y, row.z, row.w};
 #endif
-            const u32 x0 = xchg(nrow.x), x1 = xchg(nrow.y), x2 = xchg(nrow.z), x3 = xchg(nrow.w), xo = xchg(nrow.off);
             row.x = mine ? nrow.x : x0; row.y = mine ? nrow.y : x1; row.z = mine ? nrow.z : x2; row.w = mine ? nrow.w : x3;
             row.off = mine ? nrow.off : xo;
             slotn = 1;
             if (NB == 1) {
-                const u32 xh = xchg(hn_spec);
                 hctx = mine ? hn_spec : xh;
                 vm_commit(c8 - 256u);
                 c8 = 1;
@@ -348,6 +405,7 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
         cur_b = (i32)(int8_t)t8[cur_s];
         publish(1, cur_v, cur_b);
         lds_barrier();
+        load_cands(1);
     }
     for (;;) {
         cycle(I0{}, I0{});
@@ -362,6 +420,9 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
     }
     // (the last nibble's row is not written back: the slot is re-initialised for the next block)
     if ((S.lane & 1) == 0 && bl < bpw) reinterpret_cast<i32 *>(lds + S.L.stat_off)[ci * bpw + bl] = status;
+#ifdef ZPD_PROF
+    prof.flush(ci);
+#endif
 #undef ZPD_LOAD_ROWS
 }
 
@@ -425,18 +486,34 @@ __device__ __forceinline__ void dcoder_loop(const StageArgs &S, DecState &X)
         }
     };
 
+#ifdef ZPD_PROF
+    Prof prof; prof.init(blockIdx.x == 0);
+#endif
     bool dead = !S.active;                             // the block has ended (EOF, output full) or the lane has none
     bool got_first = false;
+    bool pend_store = false;
+    u32 pend_pos = 0, pend_val = 0;
+    dec_request(0u);
+    dec_adopt();
+    dec_request(0u);                                   // (adopted by the first byte iteration)
     if (S.active) {
-        dec_request(0u);
-        dec_adopt();
-        dec_request(0u);                               // (adopted by the first byte iteration)
         for (int k = 0; k < 4; k++) { const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c; }
     }
     u32 yprev = 0;
     lds_barrier();                                     // the components have published the first bit's entries
     for (;;) {
-        if (!dead) { dec_adopt(); dec_request(X.ipos); }
+        // (unconditional: a load inside an exec-masked branch is waited for at the branch join, at once)
+        dec_adopt();
+        // The byte decoded in the last iteration is stored HERE, behind the wait for the window that was requested a whole
+        // byte ago (vmcnt retires in order: a store issued at the end of the last iteration would be waited for as well),
+        // and unconditionally -- lanes with nothing to store aim at their block's state slot (the ZPAQL registers no chain
+        // kernel uses): a store under a branch makes the compiler wait for everything at the next use of a loaded register.
+        {
+            u8 *const sp = pend_store ? dst + pend_pos : S.slot;
+            *sp = (u8)pend_val;
+            pend_store = false;
+        }
+        dec_request(X.ipos);
         // ---- EOF flag: decode(0) (decoder.v:128): p = 0, mid = low
         if (!dead) {
             if (X.code <= X.low) { dead = true; X.high = X.low; } else { X.low = X.low + 1; }
@@ -469,19 +546,23 @@ __device__ __forceinline__ void dcoder_loop(const StageArgs &S, DecState &X)
             if (S.lane < bpw) ymail[(size_t)par * bpw] = y | (dead ? 2u : 0u);
             dead_pub = dead;
             yprev = y;
-            lds_barrier();
+            ZPD_BARRIER(kb);
         }
         if (!dead) {
             const u32 byte = c8 - 256u;
             if (pp && !got_first) { X.first = byte; got_first = true; }
             else {
-                if (X.opos < cap) dst[X.opos] = (u8)byte;
+                pend_store = X.opos < cap; pend_pos = X.opos; pend_val = byte;
                 X.opos++;
                 if (X.opos > cap) dead = true;
             }
         }
         if (__ballot(!dead_pub) == 0ull) break;
     }
+    if (pend_store) dst[pend_pos] = (u8)pend_val;
+#ifdef ZPD_PROF
+    prof.flush(NCH);
+#endif
 }
 
 // NCH = chain length (ICM + ISSEs); waves: NCH + the decoder
@@ -596,14 +677,18 @@ static bool dpipe_layout(const Cfg &cfg, int bpw, zpqd::DLds *L, size_t *lds_byt
     return off <= 160 * 1024;
 }
 
-// The wave-split decoder exists for the dense chains of levels 1-3.  ZPQ_DEC_PIPE=0 keeps the lane-per-component
-// decoder (tests compare the two).  A block is a lane PAIR of a component wave: at most 32 per workgroup; and a wave
-// must not live on a handful of lanes (zpq_pipe.hip): batches of fewer than 12 resident blocks stay with zpq_chain.hip.
+// The wave-split decoder exists for the dense chains of levels 1-3 and is OPT-IN (ZPQ_DEC_PIPE=1): measured on MI355X it
+// is slower than the lane-per-component decoder (level 2 x 8192: 300 vs 269 ms; DESIGN.md 4.5 has the per-wave cycle
+// breakdown) -- both are bound by the two HBM round trips per byte that nothing can be overlapped with once the LDS is
+// full of blocks, and the faster bit step leaves more of them exposed.  It stays as a third, independently written
+// device implementation that the tests compare the others with.  A block is a lane PAIR of a component wave: at most 32
+// per workgroup; and a wave must not live on a handful of lanes (zpq_pipe.hip): fewer than 12 resident blocks stay
+// with zpq_chain.hip.
 extern "C" int zpq_dpipe_applies(const DModel *M, int blocks_per_wg, int nslots)
 {
     if (nslots < 12) return 0;
     const char *ev = getenv("ZPQ_DEC_PIPE");
-    if (ev && atoi(ev) == 0) return 0;
+    if (!ev || atoi(ev) == 0) return 0;
     Cfg cfg;
     if (!zpq_chain_build_cfg(M, &cfg)) return 0;
     if (cfg.has_mix2 || cfg.sparse) return 0;
@@ -613,6 +698,15 @@ extern "C" int zpq_dpipe_applies(const DModel *M, int blocks_per_wg, int nslots)
     size_t lds = 0;
     return dpipe_layout(cfg, blocks_per_wg, &L, &lds) ? 1 : 0;
 }
+
+#ifdef ZPD_PROF
+extern "C" int zpq_debug_dpipe_prof(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zpqd::zpd_prof), sizeof(unsigned long long) * 16 * 8 * 2) != hipSuccess) return ZPQ_E_INTERNAL;
+    if (reset) { static unsigned long long z[16 * 8 * 2]; if (hipMemcpyToSymbol(HIP_SYMBOL(zpqd::zpd_prof), z, sizeof z) != hipSuccess) return ZPQ_E_INTERNAL; }
+    return ZPQ_OK;
+}
+#endif
 
 extern "C" int zpq_launch_dpipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream)
 {
@@ -624,6 +718,7 @@ extern "C" int zpq_launch_dpipe(const DBatch *B, const DModel *hostM, int nwg, i
         const int nslots = B->nslots;
         int cap = cfg.blocks_per_wg < 32 ? cfg.blocks_per_wg : 32;
         int per = blocks_per_wg < 16 ? (cap < 16 ? cap : 16) : (blocks_per_wg < cap ? blocks_per_wg : cap);
+        { const char *ev = getenv("ZPQ_DPIPE_PER"); if (ev && atoi(ev) >= 9 && atoi(ev) <= cap) per = atoi(ev); }
         nwg = (nslots + per - 1) / per;
         blocks_per_wg = (nslots + nwg - 1) / nwg;
     }
@@ -631,7 +726,7 @@ extern "C" int zpq_launch_dpipe(const DBatch *B, const DModel *hostM, int nwg, i
     zpqd::DLds L;
     size_t lds = 0;
     if (!dpipe_layout(cfg, blocks_per_wg, &L, &lds)) return ZPQ_E_INTERNAL;
-    if (lds < 81 * 1024) lds = 81 * 1024;                     // one workgroup per CU, one wave per SIMD (zpq_pipe.hip)
+    { const char *ev = getenv("ZPQ_DPIPE_SHARE"); if (!(ev && atoi(ev) == 1) && lds < 81 * 1024) lds = 81 * 1024; }   // one workgroup per CU unless asked
 #define ZPD_LAUNCH(N)                                                                                                \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void *)zpqd::k_dpipe<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
