@@ -162,15 +162,15 @@ def kernel_src_sha():
 
 def measured_traffic(dom_name, nb):
     """HBM bytes per launch of the dominant kernel from the round's rocprofv3 --pmc passes
-    (profiles/r02_pmc.json, written by tools/pmc_collect.py).  Only reported when that profile was
+    (profiles/r03_pmc.json, written by tools/pmc_collect.py).  Only reported when that profile was
     taken on exactly the kernel source this run executes; otherwise null, with the reason."""
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if not os.path.exists(pmc):
         return None, "no PMC profile for this round yet"
     try:
         pj = json.load(open(pmc))
         if pj.get("_kernel_src_sha") != kernel_src_sha():
-            return None, "profiles/r02_pmc.json was taken on another kernel source (%s)" % pj.get("_kernel_src_sha")
+            return None, "profiles/r03_pmc.json was taken on another kernel source (%s)" % pj.get("_kernel_src_sha")
         t = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
         if t is None:
             return None, "kernel not in profile"

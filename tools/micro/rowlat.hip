@@ -5,7 +5,7 @@
 //
 // One workgroup of WPC waves per CU; every lane owns a private TABLE_BYTES region ("hash table").  Per iteration:
 //   t0; issue the loads of pattern P; `lead` dependent VALU instructions (work that overlaps the fetch);
-//   s_waitcnt vmcnt(0); t1          -> latency beyond the lead = t1 - t0 (s_memtime, 100 MHz, averaged)
+//   s_waitcnt vmcnt(0); t1          -> latency beyond the lead = t1 - t0 (s_memtime, averaged)
 //   one 16-byte store to the line just read (the row write-back), `gap` dependent VALU instructions (the nibble's
 //   bit steps), workgroup barrier (the blocks of a CU stay in lockstep).
 // Patterns (lines requested per lane and nibble):
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(512) k_rowlat(unsigned char *base, unsigned lo
         for (int w = 0; w < gap; w++) acc = acc * 1664525u + 1013904223u;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (lane == 0) { out[(blockIdx.x * nw + wave) * 2] = (unsigned)(lat * 24 / iters); out[(blockIdx.x * nw + wave) * 2 + 1] = acc; }
+    if (lane == 0) { out[(blockIdx.x * nw + wave) * 2] = (unsigned)(lat / iters); out[(blockIdx.x * nw + wave) * 2 + 1] = acc; }
 }
 
 int main(int argc, char **argv)
@@ -72,7 +72,7 @@ int main(int argc, char **argv)
     hipMalloc(&d, ncu * 8 * 2 * 4);
     hipFuncSetAttribute((const void *)k_rowlat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("table %llu KiB per lane(-pair), buffer %llu MiB; latency = s_memtime ticks x24 (cycles at 2.4 GHz), wave 0 of CU 0\n", table >> 10, total >> 20);
+    printf("table %llu KiB per lane(-pair), buffer %llu MiB; latency = s_memtime ticks (shader cycles on gfx950), wave 0 of CU 0\n", table >> 10, total >> 20);
     const int iters = 4000;
     for (int st = 0; st <= 1; st++)
     for (int wpc = 1; wpc <= 8; wpc *= 2)

@@ -14,5 +14,5 @@ for p in "FETCH_SIZE" "WRITE_SIZE" "$P1" "$P2"; do
   i=$((i+1))
   rocprofv3 --pmc $p -d $out/pmc$i -o pmc$i --output-format csv -- $B --steps 1 --warmup 0 > $out/pmc$i.log 2>&1
 done
-python3 tools/pmc_collect.py $out $out/r02 > $out/collect.log 2>&1
+python3 tools/pmc_collect.py $out $out/${ROUND:-r03} > $out/collect.log 2>&1
 tail -5 $out/kt.log; cat $out/collect.log | head -40

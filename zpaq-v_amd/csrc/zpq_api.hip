@@ -314,6 +314,7 @@ struct BatchArgs {
 // What a batch call will launch: kernel family, slot layout, resident slots and grid.
 struct Plan {
     bool chain = false, lanes = false;
+    bool touch = false;          // dense tables that are not cleared: "touched" bitmaps (zpq_touch_layout)
     uint32_t sp = 0;             // compact line store capacity (lines), 0 = dense tables
     const DModel *M = nullptr;   // layout the kernels see (dense or compact)
     int nslots = 0, grid = 0, bpw = 0;
@@ -339,12 +340,17 @@ static int plan_chain(zpq_ctx *c, const DModel &M, int nblocks, int *nslots_out,
     return ZPQ_OK;
 }
 
-static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P)
+extern "C" int zpq_chain_touch_decode(const DModel *M);   // the decoder of this (dense) model reads rows through "touched" bitmaps
+extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots);   // the wave-pipelined encoder codes this plan
+extern "C" int zpq_pipe_touch(void);                                                // ... and reads rows through the bitmaps (timing builds only)
+
+static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P, int decode = 0)
 {
     P->chain = m->d.fast_kind && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
                !trace && !own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
-    static thread_local DModel sparse_layout;
+    static thread_local DModel sparse_layout, touch_layout;
     P->sp = 0;
+    P->touch = false;
     P->M = &m->d;
     // everything else with up to 64 components: one block per wave, lane i = component i
     P->lanes = !P->chain && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY | ZB_KEEP_STATE)) &&
@@ -376,6 +382,16 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
         else {
             if (rcd != ZPQ_OK) return rcd;
             nslots = dn; grid = dg; bpw = db;
+            // Dense tables WITHOUT clearing (12 MiB per level-2 block), one "touched" bit per row instead: built for the
+            // wave-pipelined encoder and the two-hypothesis decoder, parity-green, measured slower than the clearing it saves
+            //  -- only the -DZPP_TOUCH / -DZPQ_TOUCH_DEC timing builds take this path (ZPQ_TOUCH=0: not even they).
+            const char *tv = getenv("ZPQ_TOUCH");
+            int tn = 0, tg = 0, tb = 0;
+            const bool kernel_ok = decode ? zpq_chain_touch_decode(&m->d) != 0 : (zpq_pipe_touch() && zpq_pipe_applies(&m->d, db, dn) != 0);
+            if (!(tv && atoi(tv) == 0) && kernel_ok && zpq_touch_layout(m->d, &touch_layout) &&
+                plan_chain(c, touch_layout, nblocks, &tn, &tg, &tb) == ZPQ_OK && (decode || zpq_pipe_applies(&touch_layout, tb, tn))) {
+                P->touch = true; P->M = &touch_layout; nslots = tn; grid = tg; bpw = tb;
+            }
         }
     } else {
         const DModel &M = *P->M;
@@ -409,13 +425,13 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (a.own_slot && a.nblocks != 1) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
     Plan P;
-    int rc = plan_batch(c, m, a.flags, a.nblocks, a.trace != nullptr, a.own_slot != nullptr, &P);
+    int rc = plan_batch(c, m, a.flags, a.nblocks, a.trace != nullptr, a.own_slot != nullptr, &P, decode);
     if (rc != ZPQ_OK) return rc;
     const DModel &M = *P.M;
     const bool want_chain = P.chain, want_lanes = P.lanes;
     const int nslots = P.nslots, grid = P.grid, bpw = P.bpw;
     DevModel dm;
-    rc = get_dev_model(c, m, M, P.sp, &dm);
+    rc = get_dev_model(c, m, M, P.touch ? 0xFFFFFFFEu : P.sp, &dm);
     if (rc != ZPQ_OK) return rc;
 
     DBatch B;
@@ -589,7 +605,7 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
 {
     HIPCK(hipSetDevice(c->device));
     Plan P0;
-    int rc = plan_batch(c, m, flags, nblocks, false, false, &P0);
+    int rc = plan_batch(c, m, flags, nblocks, false, false, &P0, decode);
     if (rc != ZPQ_OK) return rc;
     // Rounds only where overlapping transfers with coding can pay: a batch that exceeds the resident capacity AND
     // moves a sizeable amount of data.  Smaller batches go as one launch (blocks beyond the capacity are worked off

@@ -206,6 +206,17 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // every row access of this lane is tbase + a 32-bit byte offset: the dense table, or the store's line array
     // (offsets, not pointers, so that the h0 ^ 16 / ^ 32 neighbours stay provably global addresses)
     u8 *const tbase = hashed ? (sp_cap ? slot + C.sp_line_off : slot + C.ht_off) : slot;
+    // "touched" bitmap of a dense table that is not cleared (two-hypothesis decoder; zpq_touch_layout): one bit per row.
+    // Built, parity-green and MEASURED SLOWER (level 2 decode 283.6 ms against 261 ms with the 15 ms of clearing; the code
+    // alone, switched off at run time, cost 12 ms): one more load per request in the in-order vmcnt queue, twelve selects,
+    // one more register to exchange between the copies.  Compiled only with -DZPQ_TOUCH_DEC (tools/variant.sh).
+#ifdef ZPQ_TOUCH_DEC
+    constexpr bool TOUCHC = true;
+#else
+    constexpr bool TOUCHC = false;
+#endif
+    const bool touch = TOUCHC && hashed && C.tb_off != 0;
+    u32 *const tb32 = reinterpret_cast<u32 *>(slot + (touch ? C.tb_off : 0));
     const int sizebits = C.a + 2;
     // Packed per-block state.  ISSE weights are 20-bit two's complement (clamp512k,
     // predictor.v:228-236): t32[s] = (w0 & 0xFFFFF) | (w1 << 20), t8[s] = w1 >> 12.  An ICM entry is
@@ -256,7 +267,6 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-
         const u8 *src = B.in + B.in_off[blk];
         const u32 nin = (u32)(B.in_off[blk + 1] - B.in_off[blk]);
         u8 *dst = B.out + B.out_off[blk];
@@ -414,7 +424,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // sits in its home slot, or a new line (it takes the first free slot it meets, and a new line is all
         // zero -- nothing to load), costs one memory round trip; only a line that was displaced when it
         // was claimed needs a second one for its rows, and only a full group is walked past.
-#define ZPQ_PREFETCH(A_, B_, C_, tags_, po_, chk_, key_, si_, off_, hc_, c8v_)          \
+#define ZPQ_PREFETCH(A_, B_, C_, tags_, po_, chk_, key_, si_, off_, tw_, hc_, c8v_)     \
     do {                                                                                \
         const u32 cx_ = (hc_) + 16u * (c8v_);                                           \
         chk_ = (cx_ >> sizebits) & 255u;                                                \
@@ -428,6 +438,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             pox_ = (si_ << 6) + off_;                                                   \
         }                                                                               \
         po_ = pox_;                                                                     \
+        if (HYP && TOUCHC) tw_ = tb32[touch ? (pox_ >> 9) : 0u];   /* the line's four "touched" bits (32 rows per word) */ \
         ZPQ_LOAD_ROWS(A_, B_, C_, pox_);                                                \
     } while (0)
         // Two-hypothesis decode: inside this launch a table's 64-byte lines are TRANSPOSED -- line (h0 >> 6) & 3 of every
@@ -447,8 +458,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             return swz_q ? t : h0;
         };
         auto load_rows = [&](const u32 po) { ZPQ_LOAD_ROWS(nA, nB, nC, po); };
-        auto prefetch_rows = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(nA, nB, nC, n_tags, n_po, n_chk, n_key, n_si, n_off, hc, c8v); };
-        auto prefetch_alt = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(aA, aB, aC, a_tags, a_po, a_chk, a_key, a_si, a_off, hc, c8v); };
+        u32 n_tw = 0xFFFFFFFFu, a_tw = 0xFFFFFFFFu;        // "touched" words of the requests in flight
+        auto prefetch_rows = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(nA, nB, nC, n_tags, n_po, n_chk, n_key, n_si, n_off, n_tw, hc, c8v); };
+        auto prefetch_alt = [&](const u32 hc, const u32 c8v) { ZPQ_PREFETCH(aA, aB, aC, a_tags, a_po, a_chk, a_key, a_si, a_off, a_tw, hc, c8v); };
         // Consume the rows requested one nibble ago, THEN write the finished row back (so that
         // the wait for the loads does not also wait for a just-issued store), then the caller
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
@@ -483,6 +495,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 };
                 nA = sel4(sel_alt, aA, nA); nB = sel4(sel_alt, aB, nB); nC = sel4(sel_alt, aC, nC);
                 n_po = sel_alt ? a_po : n_po; n_chk = sel_alt ? a_chk : n_chk;
+                if (HYP && TOUCHC) n_tw = sel_alt ? a_tw : n_tw;
                 if (SPARSE) {
                     n_tags = sel4(sel_alt, a_tags, n_tags);
                     n_key = sel_alt ? a_key : n_key; n_si = sel_alt ? a_si : n_si; n_off = sel_alt ? a_off : n_off;
@@ -528,6 +541,18 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     load_rows(n_po);
                 }
             }
+            u32 tw_line = 0xFFFFFFFFu;
+            if constexpr (HYP && TOUCHC) {
+                // a row of a table that is never cleared counts only once it has been written: untouched rows read as zeros
+                tw_line = touch ? n_tw : 0xFFFFFFFFu;
+                const u32 rb = (n_po >> 4) & 31u;
+                const u32x4 z4 = {0, 0, 0, 0};
+                const bool ta = ((tw_line >> rb) & 1u) != 0, tb = ((tw_line >> (rb ^ 1u)) & 1u) != 0, tc = ((tw_line >> (rb ^ 2u)) & 1u) != 0;
+                nA = u32x4{ta ? nA.x : 0u, ta ? nA.y : 0u, ta ? nA.z : 0u, ta ? nA.w : 0u};
+                nB = u32x4{tb ? nB.x : 0u, tb ? nB.y : 0u, tb ? nB.z : 0u, tb ? nB.w : 0u};
+                nC = u32x4{tc ? nC.x : 0u, tc ? nC.y : 0u, tc ? nC.z : 0u, tc ? nC.w : 0u};
+                (void)z4;
+            }
             const u32x4 Rp = {X.r0, X.r1, X.r2, X.r3};
             const u32 poff = roff;
             const bool fa = have_prev && n_po == poff;
@@ -540,6 +565,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const u32 x0 = xchg(X.r0), x1 = xchg(X.r1), x2 = xchg(X.r2), x3 = xchg(X.r3), xo = xchg(roff);
                 X.r0 = row_mine ? X.r0 : x0; X.r1 = row_mine ? X.r1 : x1; X.r2 = row_mine ? X.r2 : x2; X.r3 = row_mine ? X.r3 : x3;
                 roff = row_mine ? roff : xo;
+                if (TOUCHC) { const u32 xt = xchg(tw_line); tw_line = row_mine ? tw_line : xt; }
             }
             // keep the stores BELOW the wait for the loads above (vmcnt is in-order: a store issued
             // first would be waited for as well)
@@ -556,6 +582,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
 #ifndef ZPQ_DEBUG_NO_ROWS
             if (have_prev && hashed && (!HYP || hyp == 0)) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;   // (both copies hold the same row)
+            if constexpr (HYP && TOUCHC) {
+                // the row this nibble works on counts as written from now on (it is stored when the nibble ends; until then a
+                // request that meets it takes it from the registers)
+                const u32 nbit = 1u << ((roff >> 4) & 31u);
+                if (touch && hyp == 0 && (tw_line & nbit) == 0u) tb32[roff >> 9] = tw_line | nbit;
+            }
 #endif
         };
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
@@ -1328,6 +1360,19 @@ extern "C" int zpq_chain_max_wgs(const DModel *M, int cus)
 {
     (void)M;
     return cus;   // one workgroup per CU (LDS-bound)
+}
+
+// The two-hypothesis decoder (dense short chains, levels 1-2) reads hash rows through "touched" bitmaps when the slot
+// layout carries them (zpq_touch_layout); the wave-split decoder (opt-in) does not.
+extern "C" int zpq_chain_touch_decode(const DModel *M)
+{
+    Cfg cfg;
+    const char *ev = getenv("ZPQ_DEC_PIPE");
+    if (ev && atoi(ev) != 0) return 0;
+#ifndef ZPQ_TOUCH_DEC
+    return 0;                                                // (measured slower: see `touch` in k_chain)
+#endif
+    return build_cfg(M, &cfg) && !cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && cfg.g == 8 ? 1 : 0;
 }
 
 // striped host transfers (HIO kernels) exist for the dense short chains: levels 1 and 2

@@ -25,6 +25,9 @@ struct DComp {
     uint32_t a16_fill;           // initial u16 value of every a16 entry
     uint32_t sp_cap;             // 0 = dense hash table; else capacity (lines, a multiple of 4) of the compact line store
     uint64_t cm_off, ht_off, a16_off;  // byte offsets inside the state slot
+    uint64_t tb_off;             // 0, or: "touched" bitmap of this dense hash table (one bit per 16-byte row, inside the zeroed part of
+                                 // the slot); the table itself then lies BEHIND the zeroed part and is never cleared -- a row whose
+                                 // bit is clear reads as zeros (zpq_touch_layout, zpq_chain.hip's two-hypothesis decoder)
     uint64_t sp_tag_off, sp_line_off;  // compact line store: u32 tags[cap] (dense line index + 1, 0 = free) inside the zeroed
                                        // part of the slot, 64-B lines[cap] behind it (a line is zeroed when it is claimed)
 };

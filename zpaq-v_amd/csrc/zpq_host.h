@@ -27,6 +27,11 @@ uint64_t tables_fnv(int which);
 // (zero_bytes) then ends before the stores' line arrays: a line is cleared when it is claimed.
 bool zpq_sparse_layout(const DModel &dense, uint32_t cap, DModel *out);
 
+// Re-lay a model's state slot so that every ICM/ISSE hash table of at least 64 KiB needs no clearing: the table moves behind
+// the zeroed part of the slot and gets a "touched" bitmap (one bit per 16-byte row = 1/128 of the table) inside it.  A
+// level-2 block then clears 0.4 MiB instead of 12 MiB.  false if no table qualifies.
+bool zpq_touch_layout(const DModel &dense, DModel *out);
+
 // The HCOMP shape every shipped level >= 2 uses (levels.v:126-141 and on):
 //   b=c c-- *c=a d=0 (hash *d=a d++) x K  hash *d=a halt
 // leaves H[k] = hash^(k+1)(byte, previous byte) for k <= K and never touches H beyond.  Returns the

@@ -471,6 +471,34 @@ bool zpq_sparse_layout(const DModel &dense, uint32_t cap, DModel *out)
     return any;
 }
 
+bool zpq_touch_layout(const DModel &dense, DModel *out)
+{
+    *out = dense;
+    DModel &D = *out;
+    bool any = false;
+    uint64_t off = D.m_off;
+    off = align_up(off + D.mlen, 256);
+    auto take = [&](uint64_t bytes) { const uint64_t o = off; off = align_up(off + bytes, 256); return o; };
+    for (int i = 0; i < D.n; i++) {
+        DComp &c = D.comp[i];
+        c.sp_cap = 0; c.tb_off = 0;
+        if (c.cm_len) c.cm_off = take(4ull * c.cm_len);
+        if (c.ht_len) {
+            const bool hashed = c.type == ZT_ICM || c.type == ZT_ISSE;
+            if (hashed && c.ht_len >= 65536u) { c.tb_off = take(c.ht_len / 128u); c.ht_off = 0; any = true; }
+            else c.ht_off = take(c.ht_len);
+        }
+        if (c.a16_len) c.a16_off = take(2ull * c.a16_len);
+    }
+    D.zero_bytes = align_up(off, 256);
+    for (int i = 0; i < D.n; i++) {
+        DComp &c = D.comp[i];
+        if (c.tb_off) c.ht_off = take(c.ht_len);
+    }
+    D.slot_bytes = align_up(off, 256);
+    return any;
+}
+
 extern "C" int zpq_model_create_level(int level, zpq_model **out)
 {
     uint8_t h[128];

@@ -124,6 +124,7 @@ struct InWin {
 struct Req {
     u32x4 A, B, C, tags;
     u32 po, chk, key, si, off;
+    u32 tw;              // dense table that is not cleared (zpq_touch_layout): the word holding the line's four "touched" bits
 };
 // a nibble's bit-history row (byte 0 = check) and its tbase offset
 struct Row {
@@ -160,6 +161,19 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
     u8 *const slot = S.slot;
     u32 *const sp_tags = reinterpret_cast<u32 *>(slot + C.sp_tag_off);
     u8 *const tbase = sp_cap ? slot + C.sp_line_off : slot + C.ht_off;
+    // A dense table may come WITHOUT having been cleared (zpq_touch_layout: 12 MiB per level-2 block otherwise): one
+    // "touched" bit per 16-byte row says whether the row has been written in this block; an untouched row reads as zeros.
+    // Built, parity-green and MEASURED: level 2 encode 135-145 ms against 123-126 ms with the 15 ms of clearing (level 1 133
+    // against 136, level 3 dense 167 against 167.5) -- the extra load per request, the twelve selects and the word store cost
+    // what the clearing costs.  Compiled only with -DZPP_TOUCH (tools/variant.sh).
+#ifdef ZPP_TOUCH
+    constexpr bool TOUCHC = !SP;
+#else
+    constexpr bool TOUCHC = false;
+#endif
+    const bool touch = TOUCHC && C.tb_off != 0;
+    u32 *const tb32 = reinterpret_cast<u32 *>(slot + (touch ? C.tb_off : 0));
+    u32 tc_word = 0xFFFFFFFFu, tc_bit = 0;             // the last bit set: a request that was in flight then holds a stale word
     const int sizebits = C.a + 2;
     u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
     u8 *const t8 = S.my + cfg.lds_off8[ci];
@@ -207,6 +221,8 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         const u32 h0 = (cx * 16u) & ht_mask;
         u32 pox = h0;
         q.key = 0; q.si = 0; q.off = 0; q.tags = u32x4{0, 0, 0, 0};
+        q.tw = 0xFFFFFFFFu;
+        if (TOUCHC) q.tw = tb32[touch ? (h0 >> 9) : 0u];
         if (SP && sp_cap) {
             q.key = (h0 >> 6) + 1u;
             q.si = __umulhi(q.key * 0x9E3779B1u, sp_cap);
@@ -259,6 +275,16 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
                 ZPP_LOAD_ROWS(q, q.po);
             }
         }
+        u32 tw = 0xFFFFFFFFu;
+        if (TOUCHC) {
+            // (the bit of the nibble that was resolved while this request was in flight is not in its word yet)
+            tw = touch ? (q.tw | ((q.po >> 9) == tc_word ? tc_bit : 0u)) : 0xFFFFFFFFu;
+            const u32 rb = (q.po >> 4) & 31u;
+            const bool ta = ((tw >> rb) & 1u) != 0, tb = ((tw >> (rb ^ 1u)) & 1u) != 0, tc = ((tw >> (rb ^ 2u)) & 1u) != 0;
+            q.A = u32x4{ta ? q.A.x : 0u, ta ? q.A.y : 0u, ta ? q.A.z : 0u, ta ? q.A.w : 0u};
+            q.B = u32x4{tb ? q.B.x : 0u, tb ? q.B.y : 0u, tb ? q.B.z : 0u, tb ? q.B.w : 0u};
+            q.C = u32x4{tc ? q.C.x : 0u, tc ? q.C.y : 0u, tc ? q.C.z : 0u, tc ? q.C.w : 0u};
+        }
         const u32 pa = q.po, pb = q.po ^ 16u, pc = q.po ^ 32u;
         const bool a1 = have1 && pa == L1.off, b1 = have1 && pb == L1.off, c1 = have1 && pc == L1.off;
         const bool a2 = FWD2 && have2 && pa == L2.off, b2 = FWD2 && have2 && pb == L2.off, c2 = FWD2 && have2 && pc == L2.off;
@@ -292,6 +318,13 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         }
 #ifndef ZPP_DEBUG_NO_ROWS
         if (have1) *reinterpret_cast<u32x4 *>(tbase + poff2) = u32x4{L1.x, L1.y, L1.z, L1.w};
+        if (TOUCHC) {
+            // the resolved row counts as written from now on (it is stored when the next nibble's rows are consumed; until
+            // then every request that meets it takes it from the registers)
+            const u32 nbit = 1u << ((R.off >> 4) & 31u);
+            if (touch && (tw & nbit) == 0u) tb32[R.off >> 9] = tw | nbit;
+            tc_word = R.off >> 9; tc_bit = nbit;
+        }
 #endif
         return R;
     };
@@ -753,6 +786,16 @@ static bool pipe_layout(const Cfg &cfg, int bpw, zpqp::PipeLds *L, size_t *lds_b
 // The wave-pipelined encoder exists for the dense and line-store chains of levels 1-5.  ZPQ_ENC_PIPE=0 keeps the
 // lane-per-component encoder (tests compare the two).
 // (a batch of fewer than 12 resident blocks stays with the lane-per-component encoder: see zpq_launch_pipe)
+// 1 = this build's encoder reads dense hash rows through "touched" bitmaps (zpq_touch_layout)
+extern "C" int zpq_pipe_touch(void)
+{
+#ifdef ZPP_TOUCH
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots)
 {
     if (nslots < 12) return 0;
