@@ -64,9 +64,26 @@ def cpu_baseline(level, size, host, per_thread_blocks, one_thread_blocks):
     nproc), at 16 threads and at one thread."""
     import oracle_lib as O
     try:
-        avail = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
+        visible = os.cpu_count() or 1
+    # a container may see every hardware thread of the host and still be scheduled on a few (cgroup CPU quota): the
+    # threads that can actually run at once are what "nproc" means for a baseline
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if f[0] != "max":
+                    quota = max(1, int(round(int(f[0]) / int(f[1]))))
+            else:
+                q = int(f[0])
+                if q > 0:
+                    quota = max(1, int(round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    avail = min(visible, quota) if quota else visible
     hdr = O.level_header(level)
 
     def timed(nb, nthreads):
@@ -83,7 +100,7 @@ def cpu_baseline(level, size, host, per_thread_blocks, one_thread_blocks):
                 "decomp_MBps": round(B / (t2 - t1) / 1e6, 3), "cores": nthreads, "blocks": nb, "seconds": round(t2 - t0, 2)}
 
     # one thread codes a 64 KiB block both ways in ~30 ms: 32 blocks per thread keep every leg at a few seconds
-    full = timed(per_thread_blocks * avail, avail)
+    full = timed(per_thread_blocks * avail if avail <= 64 else 8 * avail, avail)
     t16 = timed(per_thread_blocks * 4 * min(avail, 16), min(avail, 16))
     one = timed(one_thread_blocks, 1)
     return {
@@ -91,13 +108,57 @@ def cpu_baseline(level, size, host, per_thread_blocks, one_thread_blocks):
         "comp_MBps": full["comp_MBps"], "decomp_MBps": full["decomp_MBps"], "seconds": full["seconds"],
         "blocks": full["blocks"],
         "sixteen_threads": t16, "one_thread": one,
-        "nproc": os.cpu_count(), "nproc_available": avail, "cpu_model": cpu_model_string(),
+        "nproc": os.cpu_count(), "nproc_visible": visible, "cgroup_cpu_quota": quota, "nproc_available": avail,
+        "cpu_model": cpu_model_string(),
         "sample": "the first %d blocks of the headline batch (64 KiB, classes b mod 4), level %d, C oracle "
                   "compress+decompress on %d pthreads = every hardware thread this process may run on (blocks divided "
                   "statically; per-block table alloc+zero-fill included); sixteen_threads / one_thread = the first %d / %d "
                   "of those blocks on 16 / 1 threads.  A real V build adds bounds checks and interface dispatch per byte, "
                   "so it would be slower than this port." % (full["blocks"], level, avail, t16["blocks"], one["blocks"]),
     }
+
+
+def incl_pcie_run(z, ctx, model, flags, size, cap, nblk, arr2d, what):
+    """One batch through the host-pointer entry points (what a V front end holding host buffers calls): H2D + kernel + D2H
+    inside each call.  Buffers come from zpq_host_alloc (pinned); the decoder is handed the coded streams packed back to
+    back, as an archive holds them.  Returns the second of two calls."""
+    import numpy as np
+    L = z.lib()
+    nbytes = nblk * size
+    in_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(size)
+    out_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(cap)
+    p_src, p_out, p_dec = z.PinnedArray(nbytes), z.PinnedArray(nblk * cap), z.PinnedArray(nbytes)
+    p_src.array[:] = arr2d.reshape(-1)
+    olen = np.zeros(nblk, dtype=np.uint32); st = np.zeros(nblk, dtype=np.int32)
+    dlen = np.zeros(nblk, dtype=np.uint32); dst = np.zeros(nblk, dtype=np.int32)
+    r = {}
+    p_cod = None
+    for rep in range(2):
+        t0 = time.time()
+        rc1 = L.zpq_encode_blocks(ctx.h, model.h, nblk, p_src.array.ctypes.data, in_off.ctypes.data, flags,
+                                  p_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
+        t1 = time.time()
+        # pack the coded streams (outside the timed calls: an archive already holds them like this)
+        c_off = np.zeros(nblk + 1, dtype=np.uint64)
+        c_off[1:] = np.cumsum(olen.astype(np.uint64))
+        if rep == 0:
+            p_cod = z.PinnedArray(int(c_off[-1]) + 16)
+            for i in range(nblk):
+                p_cod.array[int(c_off[i]):int(c_off[i + 1])] = p_out.array[i * cap:i * cap + int(olen[i])]
+        t2 = time.time()
+        rc2 = L.zpq_decode_blocks(ctx.h, model.h, nblk, p_cod.array.ctypes.data, c_off.ctypes.data, flags,
+                                  p_dec.array.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, None, None, None,
+                                  dst.ctypes.data)
+        t3 = time.time()
+        tt = (t1 - t0) + (t3 - t2)
+        r = {"value": round(nbytes / tt / 1e6, 1), "unit": "MB/s", "blocks": nblk, "rounds": -(-nblk // ctx.last_slots),
+             "comp_MBps": round(nbytes / (t1 - t0) / 1e6, 1), "decomp_MBps": round(nbytes / (t3 - t2) / 1e6, 1),
+             "ok": bool(rc1 == 0 and rc2 == 0 and (st == 0).all() and (dst == 0).all()
+                        and np.array_equal(p_dec.array, p_src.array)),
+             "what": what}
+    for pa in (p_src, p_out, p_dec, p_cod):
+        pa.free()
+    return r
 
 
 class ResidentBatch:
@@ -365,40 +426,7 @@ def main():
             L = z.lib()
 
             def incl_pcie(nblk, arr2d, what):
-                nbytes = nblk * size
-                in_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(size)
-                out_off = np.arange(nblk + 1, dtype=np.uint64) * np.uint64(cap)
-                p_src, p_out, p_dec = z.PinnedArray(nbytes), z.PinnedArray(nblk * cap), z.PinnedArray(nbytes)
-                p_src.array[:] = arr2d.reshape(-1)
-                olen = np.zeros(nblk, dtype=np.uint32); st = np.zeros(nblk, dtype=np.int32)
-                dlen = np.zeros(nblk, dtype=np.uint32); dst = np.zeros(nblk, dtype=np.int32)
-                r = {}
-                for rep in range(2):
-                    t0 = time.time()
-                    rc1 = L.zpq_encode_blocks(ctx.h, model.h, nblk, p_src.array.ctypes.data, in_off.ctypes.data, flags,
-                                              p_out.array.ctypes.data, out_off.ctypes.data, olen.ctypes.data, st.ctypes.data)
-                    t1 = time.time()
-                    # pack the coded streams (outside the timed calls: an archive already holds them like this)
-                    c_off = np.zeros(nblk + 1, dtype=np.uint64)
-                    c_off[1:] = np.cumsum(olen.astype(np.uint64))
-                    if rep == 0:
-                        p_cod = z.PinnedArray(int(c_off[-1]) + 16)
-                        for i in range(nblk):
-                            p_cod.array[int(c_off[i]):int(c_off[i + 1])] = p_out.array[i * cap:i * cap + int(olen[i])]
-                    t2 = time.time()
-                    rc2 = L.zpq_decode_blocks(ctx.h, model.h, nblk, p_cod.array.ctypes.data, c_off.ctypes.data, flags,
-                                              p_dec.array.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, None, None, None,
-                                              dst.ctypes.data)
-                    t3 = time.time()
-                    tt = (t1 - t0) + (t3 - t2)
-                    r = {"value": round(nbytes / tt / 1e6, 1), "unit": "MB/s", "blocks": nblk, "rounds": -(-nblk // ctx.last_slots),
-                         "comp_MBps": round(nbytes / (t1 - t0) / 1e6, 1), "decomp_MBps": round(nbytes / (t3 - t2) / 1e6, 1),
-                         "ok": bool(rc1 == 0 and rc2 == 0 and (st == 0).all() and (dst == 0).all()
-                                    and np.array_equal(p_dec.array, p_src.array)),
-                         "what": what}
-                for pa in (p_src, p_out, p_dec, p_cod):
-                    pa.free()
-                return r
+                return incl_pcie_run(z, ctx, model, flags, size, cap, nblk, arr2d, what)
 
             pc = incl_pcie(nb, host, "zpq_encode_blocks + zpq_decode_blocks on pinned host buffers (zpq_host_alloc), the headline batch in "
                                      "one round: striped upload / download beside the kernel (host_pipeline, HIO kernels); second of two calls")
@@ -419,7 +447,7 @@ def main():
             from inputs import C4B
             secondary = {}
 
-            def run_cfg(key, what, mdl, want_nb, A_minus_r, capmul, names_):
+            def run_cfg(key, what, mdl, want_nb, A_minus_r, capmul, names_, pcie=False):
                 cap_res = ctx.resident_capacity(mdl, flags)
                 n = min(want_nb, cap_res) if want_nb else cap_res
                 arr = host[:n] if n <= nb else np.concatenate([host] * ((n + nb - 1) // nb))[:n]
@@ -436,17 +464,25 @@ def main():
                     "kernel_ms": {b.enc_name: round(e, 2), b.dec_name: round(dd, 2)},
                     "roundtrip_bit_exact": b.ok(d),
                     "roofline": roofline_of(A_minus_r, r, n, size, e, dd, (b.enc_name, b.dec_name))}
+                cap_ = b.cap
                 del b, d
                 torch.cuda.empty_cache()
+                if pcie:
+                    # the same batch through the host-pointer entry points (pinned buffers; the line-store kernels have no
+                    # striped transfers: upload, kernel, download in turn)
+                    pc = incl_pcie_run(z, ctx, mdl, flags, size, cap_, n, np.ascontiguousarray(arr), "zpq_encode_blocks + zpq_decode_blocks on "
+                                       "pinned host buffers, one round, second of two calls")
+                    pc["fraction_of_device_resident"] = round(pc["value"] / secondary[key]["roundtrip_MBps"], 4)
+                    secondary[key]["incl_pcie"] = pc
 
             run_cfg("C2_level1", "level 1 (%s, levels.v:53-92), 4096 x 64 KiB" % LEVEL_NAMES[1], z.Model(level=1), 4096,
                     ALG_BYTES_PER_INPUT_BYTE_L[1], 1.125, None)
             run_cfg("level3", "level 3 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[3], z.Model(level=3), 0,
-                    ALG_BYTES_PER_INPUT_BYTE_L[3], 1.125, None)
+                    ALG_BYTES_PER_INPUT_BYTE_L[3], 1.125, None, pcie=True)
             run_cfg("level4", "level 4 (%s), 64 KiB blocks at resident capacity" % LEVEL_NAMES[4], z.Model(level=4), 0,
                     ALG_BYTES_PER_INPUT_BYTE_L[4], 1.125, None)
             run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
-                    z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None)
+                    z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None, pcie=True)
             run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 64 KiB blocks at resident "
                                           "capacity (four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
             res["secondary"] = secondary

@@ -61,6 +61,7 @@ struct PipeLds {
     int32_t link_off;    // uint4 link[NCH][2][blocks_per_wg]
     int32_t stat_off;    // int32 stat[NCH][blocks_per_wg]
     int32_t misc_off;    // u32: longest block of the round
+    int32_t st_off;      // k_pipe2: uint2 states[NCH - 1][2][blocks_per_wg] (a byte's eight bit-history states per ISSE)
 };
 
 struct StageArgs {
@@ -508,6 +509,266 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
 #undef ZPP_LOAD_ROWS
 }
 
+// ------------------------------------------------------------------ a component's stage SPLIT in two (levels 1-2)
+// An ISSE stage is the pipeline's period (~100 instructions per bit against the ICM's 88 and the coder's 26 + loops), and
+// half of it never touches a weight: finding the nibble's row (find_ht, forwarding, requests), walking the bit-history
+// states through it, writing the next state back.  All of that is a function of the INPUT alone.  So the stage is cut:
+//   * hist_loop: rows and states.  Per byte it leaves the eight states the byte's bits are predicted from (8 bytes per
+//     block) in LDS;
+//   * pred_loop: weights.  One iteration later it takes those states and its predecessor's predictions, predicts, trains,
+//     hands its predictions on.
+// Waves are placed so that the two history waves share one SIMD (no dependent LDS round trip in them: they interleave
+// well) and the coder shares one with a prediction wave: k_pipe2 below.
+template <int NCH, bool HIO>
+__device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
+{
+    const DBatch &B = *S.B;
+    const DModel &M = *B.model;
+    u8 *const lds = S.lds;
+    const u8 *s_ns = lds + LDS_NS;
+    const int ci = S.ci;
+    const DComp &C = M.comp[ci];
+    const u32 ht_mask = C.ht_len - 16u;
+    u8 *const tbase = S.slot + C.ht_off;
+    const int sizebits = C.a + 2;
+    uint2 *const st_out = reinterpret_cast<uint2 *>(lds + S.L.st_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
+    const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
+    const u32 total = S.total;
+    InWin W;
+    if (S.active) W.open(S.src, S.nin, B.in_off);
+    u32 prev = 0, m4 = 0, b4 = 0, hctx = 0;
+    u32 slotn = 1;
+    u32 ch = 0;
+#define ZPH_LOAD_ROWS(q_, po_)                                                          \
+    do {                                                                                \
+        q_.A = *reinterpret_cast<const u32x4 *>(tbase + (po_));                         \
+        q_.B = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 16u));                 \
+        q_.C = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 32u));                 \
+    } while (0)
+    auto request = [&](const u32 hc, const u32 c8v) -> Req {
+        Req q;
+        const u32 cx = hc + 16u * c8v;
+        q.chk = (cx >> sizebits) & 255u;
+        q.po = (cx * 16u) & ht_mask;
+        q.key = 0; q.si = 0; q.off = 0; q.tags = u32x4{0, 0, 0, 0}; q.tw = 0;
+        ZPH_LOAD_ROWS(q, q.po);
+        return q;
+    };
+    // find_ht with the rows of the two nibbles finished since the request went out taken from registers (comp_loop, FWD2)
+    auto consume = [&](Req q, const bool have1, const Row L1, const bool have2, const Row L2) -> Row {
+        const u32 pa = q.po, pb = q.po ^ 16u, pc = q.po ^ 32u;
+        const bool a1 = have1 && pa == L1.off, b1 = have1 && pb == L1.off, c1 = have1 && pc == L1.off;
+        const bool a2 = have2 && pa == L2.off, b2 = have2 && pb == L2.off, c2 = have2 && pc == L2.off;
+        auto fwd = [](const bool f1, const Row &R1, const bool f2, const Row &R2, const u32x4 N) -> u32x4 {
+            return u32x4{f1 ? R1.x : (f2 ? R2.x : N.x), f1 ? R1.y : (f2 ? R2.y : N.y),
+                         f1 ? R1.z : (f2 ? R2.z : N.z), f1 ? R1.w : (f2 ? R2.w : N.w)};
+        };
+        const u32x4 A = fwd(a1, L1, a2, L2, q.A), Bq = fwd(b1, L1, b2, L2, q.B), Cq = fwd(c1, L1, c2, L2, q.C);
+        const u32 chk = q.chk;
+        const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
+        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+        const bool va = qa <= qb && qa <= qc, vb = qb < qc;             // victim order (predictor.v:513-531)
+        const bool hit = ma || mb || mc;
+        const bool ua = ma || (!hit && va);
+        const bool ub = !ua && (mb || (!hit && vb));
+        Row R;
+        R.off = ua ? pa : (ub ? pb : pc);
+        const u32 Rx = ua ? A.x : (ub ? Bq.x : Cq.x), Ry = ua ? A.y : (ub ? Bq.y : Cq.y);
+        const u32 Rz = ua ? A.z : (ub ? Bq.z : Cq.z), Rw = ua ? A.w : (ub ? Bq.w : Cq.w);
+        R.x = hit ? Rx : chk; R.y = hit ? Ry : 0u; R.z = hit ? Rz : 0u; R.w = hit ? Rw : 0u;
+        u32 poff2 = L1.off;
+        asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(poff2) : "v"(R.x), "v"(R.w));
+        if (have1) *reinterpret_cast<u32x4 *>(tbase + poff2) = u32x4{L1.x, L1.y, L1.z, L1.w};
+        return R;
+    };
+    auto run_vm = [&](const u32 byte) -> u32 {         // comp_loop
+        u32 hv = 0;
+        if (NCH != 2) {
+            u32 a = byte;
+            for (int k = 0; k <= ci; k++) a = (a + prev + 512u) * 773u;
+            hv = a;
+            prev = byte;
+        } else {
+            m4 = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
+            u32 bb = b4;
+            u32 a = 0;
+            a = (a + ((m4 >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+            a = (a + ((m4 >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+            const u32 h0v = a; bb--;
+            a = (a + ((m4 >> ((bb & 3) * 8)) & 255u) + 512u) * 773u; bb--;
+            a = (a + ((m4 >> ((bb & 3) * 8)) & 255u) + 512u) * 773u;
+            hv = (ci == 0) ? h0v : a;
+            b4 -= 3u;
+        }
+        return hv;
+    };
+    Row rowA = {0, 0, 0, 0, 0}, rowB = {0, 0, 0, 0, 0};
+    u32 cur_s = 0;
+    u32 so0 = 0, so1 = 0;                              // the byte's eight states, in coding order
+    auto bitstep = [&](auto kc, auto nbc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr int NB = decltype(nbc)::value;
+        constexpr int bit = (NB ? 3 : 7) - K;
+        constexpr int KB = 7 - bit;
+        Row &R = NB ? rowB : rowA;
+        const u32 s = cur_s;
+        const u32 yk = (ch >> bit) & 1u;
+        {
+            const u32 sv = s << ((KB & 3) * 8);
+            if (KB < 4) so0 = (KB & 3) ? (so0 | sv) : sv;
+            else so1 = (KB & 3) ? (so1 | sv) : sv;
+        }
+        if (K < 3) {
+            u32 pair;
+            if (K == 0) pair = R.x >> 16;
+            else if (K == 1) pair = R.y >> ((slotn & 1u) * 16u);
+            else pair = ((slotn & 2u) ? R.w : R.z) >> ((slotn & 1u) * 16u);
+            cur_s = yk ? ((pair >> 8) & 255u) : (pair & 255u);
+        }
+        const u32 ns01 = *reinterpret_cast<const u16 *>(s_ns + s * 4);
+        const u32 nsv = yk ? (ns01 >> 8) : (ns01 & 255u);
+        const u32 sh = (slotn & 3u) * 8u;
+        const u32 dsel = (K <= 1) ? R.x : (K == 2 ? R.y : ((slotn & 4u) ? R.w : R.z));
+        const u32 ins = (dsel & ~(255u << sh)) | (nsv << sh);
+        if (K <= 1) R.x = ins;
+        else if (K == 2) R.y = ins;
+        else { R.w = (slotn & 4u) ? ins : R.w; R.z = (slotn & 4u) ? R.z : ins; }
+        slotn = (K == 3) ? 1u : (slotn * 2u + yk);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    Req reqX, reqY;
+    {
+        const u32x4 z4 = {0, 0, 0, 0};
+        reqX.A = z4; reqX.B = z4; reqX.C = z4; reqX.tags = z4; reqX.po = 0; reqX.chk = 0; reqX.key = 0; reqX.si = 0; reqX.off = 0; reqX.tw = 0;
+        reqY = reqX;
+    }
+    if (S.active && total) {
+        reqX = request(0u, 1u);
+        const u32 ch0 = pp ? 0u : W.peek(0u);
+        reqY = request(0u, 16u | (ch0 >> 4));
+    }
+    i32 status = ZPQ_OK;
+    u32 it = 0;
+    for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+    const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
+    for (; it < it_end; it++) {
+        const u32 bi = it - (u32)delay;
+        if (S.active && bi < total) {
+            const u32 pos = pp ? (bi ? bi - 1u : 0u) : bi;
+            const u32 cb = W.byte(pos);
+            ch = (pp && bi == 0) ? 0u : cb;
+            const u32 chn = W.peek(pp ? bi : bi + 1u);
+            slotn = 1;
+            rowA = consume(reqX, bi != 0, rowB, bi != 0, rowA);
+            const u32 hnext = run_vm(ch);
+            reqX = request(hnext, 1u);                            // first nibble of the next byte
+            cur_s = (rowA.x >> 8) & 255u;
+            bitstep(I0{}, I0{});
+            bitstep(I1{}, I0{});
+            bitstep(I2{}, I0{});
+            bitstep(I3{}, I0{});
+            rowB = consume(reqY, true, rowA, bi != 0, rowB);
+            reqY = request(hnext, 16u | (chn >> 4));              // second nibble of the next byte
+            cur_s = (rowB.x >> 8) & 255u;
+            bitstep(I0{}, I1{});
+            bitstep(I1{}, I1{});
+            bitstep(I2{}, I1{});
+            bitstep(I3{}, I1{});
+            st_out[(it & 1u) * S.bpw] = make_uint2(so0, so1);
+        }
+        lds_barrier();
+    }
+    if (HIO && phase == 0 && B.gate_flag && !gate_wait(B.gate_flag)) status = ZPQ_E_INTERNAL;
+    }   // phase
+    if (S.lane < S.bpw) reinterpret_cast<i32 *>(lds + S.L.stat_off)[ci * S.bpw + S.lane] = status;
+#undef ZPH_LOAD_ROWS
+}
+
+// the weights half of an ISSE stage (see hist_loop): states from its history wave, inputs from its predecessor
+template <int NCH, bool HIO, bool IS_LAST>
+__device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
+{
+    const DBatch &B = *S.B;
+    const Cfg &cfg = *S.cfg;
+    u8 *const lds = S.lds;
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
+    const int ci = S.ci;
+    u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
+    u8 *const t8 = S.my + cfg.lds_off8[ci];
+    const uint2 *const st_in = reinterpret_cast<const uint2 *>(lds + S.L.st_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
+    const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
+    uint4 *const link_out = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)ci * 2 * S.bpw + S.lane;
+    const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
+    const u32 total = S.total;
+    InWin W;
+    if (S.active) W.open(S.src, S.nin, B.in_off);
+    u32 it = 0;
+    for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
+    const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
+    for (; it < it_end; it++) {
+        const u32 bi = it - (u32)delay;
+        if (S.active && bi < total) {
+            const u32 pos = pp ? (bi ? bi - 1u : 0u) : bi;
+            const u32 cb = W.byte(pos);
+            const u32 ch = (pp && bi == 0) ? 0u : cb;
+            const uint2 sv = st_in[((it - 1u) & 1u) * S.bpw];
+            const uint4 v = link_in[((it - 1u) & 1u) * S.bpw];
+            u32 po0 = 0, po1 = 0, po2 = 0, po3 = 0;
+            // the byte's first entry; afterwards the next bit's entry is fetched before this bit's update is stored and
+            // the update is forwarded in registers when the state repeats (comp_loop's bit step, the weights half)
+            u32 s = sv.x & 255u;
+            u32 cur_v = t32[s];
+            i32 cur_b = (i32)(int8_t)t8[s];
+#pragma unroll
+            for (int kb = 0; kb < 8; kb++) {
+                const u32 yk = (ch >> (7 - kb)) & 1u;
+                u32 sA = 0, rAv = 0;
+                i32 rAb = 0;
+                if (kb < 7) {
+                    const u32 w = (kb + 1) < 4 ? sv.x : sv.y;
+                    sA = (w >> (((kb + 1) & 3) * 8)) & 255u;
+                    rAv = t32[sA];
+                    rAb = (i32)(int8_t)t8[sA];
+                }
+                const i32 w0 = ((i32)(cur_v << 12)) >> 12;
+                const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
+                const u32 pw = (kb >> 1) == 0 ? v.x : ((kb >> 1) == 1 ? v.y : ((kb >> 1) == 2 ? v.z : v.w));
+                const i32 pin = (i32)(int16_t)(pw >> ((kb & 1) * 16));
+                const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);       // predictor.v:615-631
+                const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+                const i32 err = (yk ? 32767 : 0) - sq;                             // predictor.v:776-791
+                const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
+                const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
+                const u32 nv = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
+                const i32 nb = nw1 >> 12;
+                const u32 outv = IS_LAST ? (u32)sq | (yk << 15) : (u32)p;
+                {
+                    const u32 ov = (outv & 0xFFFFu) << ((kb & 1) * 16);
+                    if ((kb >> 1) == 0) po0 = (kb & 1) ? (po0 | ov) : ov;
+                    else if ((kb >> 1) == 1) po1 = (kb & 1) ? (po1 | ov) : ov;
+                    else if ((kb >> 1) == 2) po2 = (kb & 1) ? (po2 | ov) : ov;
+                    else po3 = (kb & 1) ? (po3 | ov) : ov;
+                }
+                t32[s] = nv;
+                t8[s] = (u8)nb;
+                if (kb < 7) {
+                    const bool same = sA == s;
+                    cur_v = same ? nv : rAv;
+                    cur_b = same ? nb : rAb;
+                    s = sA;
+                }
+            }
+            link_out[(it & 1u) * S.bpw] = make_uint4(po0, po1, po2, po3);
+        }
+        lds_barrier();
+    }
+    if (HIO && phase == 0 && B.gate_flag) (void)gate_wait(B.gate_flag);
+    }   // phase
+}
+
 // ------------------------------------------------------------------ the MIX2 stage (levels 4-5; predictor.v:587-592,776-791)
 // Component NCH mixes p[NCH-2] and p[NCH-1] with a 16-bit weight selected by (h + c8) -- with mask 255 the eight weights
 // of a byte are eight DISTINCT entries, known when the byte begins: they are loaded there (after the previous byte's
@@ -765,6 +1026,118 @@ __global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBat
     }
 }
 
+// The encoder of the dense short chains (levels 1-2) with every ISSE stage split into a history wave and a weights wave
+// (hist_loop / pred_loop): 2 * NCH waves.  Wave -> role, chosen for the SIMD a wave lands on (wave w runs on SIMD w & 3):
+//   NCH = 3 (level 2): 0 hist(1) | 1 pred(1) | 2 ICM | 3 pred(2) | 4 hist(2) [SIMD 0, with hist(1)] | 5 coder [SIMD 1, with pred(1)]
+//   NCH = 2 (level 1): 0 hist(1) | 1 pred(1) | 2 ICM | 3 coder
+// In iteration `it` the ICM works on byte it, hist(c) on byte it - (c - 1), pred(c) on byte it - c, the coder on byte it - NCH.
+template <int NCH, bool HIO>
+__global__ void __launch_bounds__(64 * 2 * NCH) k_pipe2(const DBatch B, const Cfg cfg, const PipeLds L)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const DModel &M = *B.model;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    {
+        u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
+        for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
+        u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        u8 *ns = lds + LDS_NS;
+        for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
+    }
+    __syncthreads();
+    const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int bpw = cfg.blocks_per_wg;
+    const int wg_slot0 = blockIdx.x * bpw;
+    const int nslots = B.nslots;
+    const int slot_id = wg_slot0 + lane;
+    const bool lane_on = lane < bpw && slot_id < nslots;
+    u8 *const slot = B.slots + (u64)(lane_on ? slot_id : wg_slot0) * M.slot_bytes;
+    u8 *const my = lds + LDS_STATE + (lane_on ? lane : 0) * cfg.lds_per_block;
+    u32 *const misc = reinterpret_cast<u32 *>(lds + L.misc_off);
+    const int wg_slots = min(bpw, nslots - wg_slot0);
+    // role of this wave: 0 = ICM, 1 = history of component comp, 2 = weights of component comp, 3 = coder
+    int role, comp;
+    if (NCH == 3) {
+        role = wave == 2 ? 0 : (wave == 0 || wave == 4 ? 1 : (wave == 5 ? 3 : 2));
+        comp = wave == 2 ? 0 : (wave <= 1 ? 1 : 2);
+    } else {
+        role = wave == 2 ? 0 : (wave == 0 ? 1 : (wave == 3 ? 3 : 2));
+        comp = wave == 2 ? 0 : 1;
+    }
+
+    for (int base = wg_slot0; base < B.nblocks; base += nslots) {
+        const int blk = base + lane;
+        const bool active = lane_on && blk < B.nblocks;
+        const int nact = min(wg_slots, B.nblocks - base);
+        {   // ---- Predictor.init + ZPAQL.clear for the round's blocks (k_pipe)
+            const u64 n16 = M.zero_bytes / 16;
+            const uint4 zero = make_uint4(0, 0, 0, 0);
+            for (int b = 0; b < nact; b++) {
+                uint4 *z4 = reinterpret_cast<uint4 *>(B.slots + (u64)(wg_slot0 + b) * M.slot_bytes);
+                for (u64 i = tid; i < n16; i += nthr) z4[i] = zero;
+            }
+            for (int idx = tid; idx < nact * 256; idx += nthr) {
+                const int b = idx >> 8, i = idx & 255;
+                u8 *blk_lds = lds + LDS_STATE + b * cfg.lds_per_block;
+                {
+                    const u32 cmi = B.img[i];
+                    u32 q = cmi >> 8;
+                    q = min(max(q, 1u), 32767u);
+                    const u32 wv = s_stretch[q >> 4];
+                    const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+                    const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+                    const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+                    const i32 sti = (q < 64u || q >= 32704u) ? endv : midv;
+                    reinterpret_cast<u32 *>(blk_lds + cfg.lds_off32[0])[i] = cmi | (((u32)sti & 0x1FFu) << 23);
+                    (blk_lds + cfg.lds_off8[0])[i] = (u8)(sti >> 9);
+                }
+                const u32 a0 = B.img[256 + 2 * i], a1 = B.img[257 + 2 * i];
+                for (int c = 1; c < NCH; c++) {
+                    reinterpret_cast<u32 *>(blk_lds + cfg.lds_off32[c])[i] = (a0 & 0xFFFFFu) | (a1 << 20);
+                    (blk_lds + cfg.lds_off8[c])[i] = (u8)((i32)a1 >> 12);
+                }
+            }
+            if (tid == 0) *misc = 0u;
+        }
+        __syncthreads();
+
+        StageArgs S;
+        S.B = &B; S.cfg = &cfg; S.lds = lds; S.ci = comp; S.lane = lane; S.bpw = bpw; S.active = active;
+        S.slot = slot; S.my = my; S.L = L; S.blk = (u32)blk;
+        S.src = active ? B.in + B.in_off[blk] : B.in;
+        S.nin = active ? (u32)(B.in_off[blk + 1] - B.in_off[blk]) : 0u;
+        S.dst = active ? B.out + B.out_off[blk] : B.out;
+        S.cap = active ? (u32)(B.out_off[blk + 1] - B.out_off[blk]) : 0u;
+        S.total = active ? S.nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u) : 0u;
+        if (wave == 0) atomicMax(misc, S.total);
+        __syncthreads();
+        S.iters = *misc + (u32)NCH;
+        S.split = (HIO && B.gate_flag) ? (B.gate_pos > 64u ? B.gate_pos - 64u : 0u) : S.iters;
+
+        Coder X;
+        X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
+        if (role == 0) comp_loop<NCH, false, HIO, true, false, false>(S);
+        else if (role == 1) hist_loop<NCH, HIO>(S, comp - 1);
+        else if (role == 2) { if (comp == NCH - 1) pred_loop<NCH, HIO, true>(S, comp); else pred_loop<NCH, HIO, false>(S, comp); }
+        else coder_loop<NCH, HIO>(S, X);
+        __syncthreads();
+        if (role == 3 && active) {
+            X.high = X.low;                                           // encode(1, 0): mid = low, high = mid
+            X.shift_out();
+            for (int sft = 24; sft >= 0; sft -= 8) X.put(X.high >> sft);
+            const i32 *stat = reinterpret_cast<const i32 *>(lds + L.stat_off);
+            i32 st = ZPQ_OK;
+            for (int c = 0; c < NCH; c++) { const i32 sc = stat[c * bpw + lane]; st = st ? st : sc; }
+            if (X.opos > X.cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
+            B.out_len[blk] = X.opos;
+            B.status[blk] = st;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace zpqp
 
 // ------------------------------------------------------------------ host side
@@ -779,6 +1152,8 @@ static bool pipe_layout(const Cfg &cfg, int bpw, zpqp::PipeLds *L, size_t *lds_b
     L->link_off = (int32_t)off; off += (size_t)nlinks * 2 * bpw * 16;
     L->stat_off = (int32_t)off; off += (size_t)(nch + 1) * bpw * 4;
     L->misc_off = (int32_t)off; off += 16;
+    L->st_off = (int32_t)off;
+    if (cfg.split_enc) off += (size_t)(nch - 1) * 2 * bpw * 8;
     *lds_bytes = off;
     return off <= 160 * 1024;
 }
@@ -829,6 +1204,11 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     }
     const bool hio = B->gate_flag != nullptr;
     if (hio && cfg.sparse) return ZPQ_E_INTERNAL;            // (striped uploads: dense levels 1-2, see zpq_chain_has_hio)
+    // dense levels 1-2: every ISSE stage split into a history wave and a weights wave (k_pipe2); ZPQ_ENC_SPLIT=0: one wave
+    {
+        const char *ev = getenv("ZPQ_ENC_SPLIT");
+        cfg.split_enc = (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0)) ? 1 : 0;
+    }
     cfg.blocks_per_wg = blocks_per_wg;
     zpqp::PipeLds L;
     size_t lds = 0;
@@ -843,6 +1223,17 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
         hipLaunchKernelGGL((zpqp::k_pipe<N, MX, SPv, HIOv>), dim3(nwg), dim3(64 * ((N) + ((MX) ? 2 : 1))), lds, stream, *B, cfg, L); \
     } while (0)
     if (hio && !(cfg.nch_spec == 2 || cfg.nch_spec == 3)) return ZPQ_E_INTERNAL;
+#define ZPP_LAUNCH2(N, HIOv)                                                                                         \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute((const void *)zpqp::k_pipe2<N, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((zpqp::k_pipe2<N, HIOv>), dim3(nwg), dim3(64 * 2 * (N)), lds, stream, *B, cfg, L);        \
+    } while (0)
+    if (cfg.split_enc) {
+        if (cfg.nch_spec == 2) { if (hio) ZPP_LAUNCH2(2, true); else ZPP_LAUNCH2(2, false); }
+        else { if (hio) ZPP_LAUNCH2(3, true); else ZPP_LAUNCH2(3, false); }
+        return ZPQ_OK;
+    }
+#undef ZPP_LAUNCH2
     switch (cfg.nch_spec) {
     case 2: if (cfg.sparse) ZPP_LAUNCH(2, false, true, false); else if (hio) ZPP_LAUNCH(2, false, false, true); else ZPP_LAUNCH(2, false, false, false); break;
     case 3: if (cfg.sparse) ZPP_LAUNCH(3, false, true, false); else if (hio) ZPP_LAUNCH(3, false, false, true); else ZPP_LAUNCH(3, false, false, false); break;
