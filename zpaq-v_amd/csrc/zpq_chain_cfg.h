@@ -38,7 +38,7 @@ struct Cfg {
     int32_t g;                 // lanes per block chosen on the host (8 or 16)
     int32_t nch_spec;          // compile-time specialisation picked on the host: chain length (0 = runtime path)
     int32_t sparse;            // some component uses a compact line store
-    int32_t split_enc;         // zpq_pipe.hip: the encoder runs every ISSE as a history wave + a weights wave (k_pipe2)
+    int64_t split_enc;         // zpq_pipe.hip, k_pipe2: 0, or wave -> role (4 bits each) | split components << 32 | waves << 40 | 1 << 48
     uint32_t dbg_ht_and;       // timing experiments only: AND-mask on hash-table offsets (0xFFFFFFFF = off)
     int32_t lds_dummy;         // byte offset (from LDS_STATE) of the per-workgroup dummy tables idle lanes use
     int32_t lds_mixw;          // byte offset inside the block's LDS state of u16[16]: the nibble's candidate MIX2 weights (decode)

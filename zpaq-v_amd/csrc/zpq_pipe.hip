@@ -61,7 +61,7 @@ struct PipeLds {
     int32_t link_off;    // uint4 link[NCH][2][blocks_per_wg]
     int32_t stat_off;    // int32 stat[NCH][blocks_per_wg]
     int32_t misc_off;    // u32: longest block of the round
-    int32_t st_off;      // k_pipe2: uint2 states[NCH - 1][2][blocks_per_wg] (a byte's eight bit-history states per ISSE)
+    int32_t st_off;      // k_pipe2: uint2 states[NCH][2][blocks_per_wg] (a byte's eight bit-history states per component)
 };
 
 struct StageArgs {
@@ -69,6 +69,7 @@ struct StageArgs {
     const Cfg *cfg;
     u8 *lds;
     int ci;              // stage = component index (the coder: NCH)
+    int delay;           // comp_loop: in iteration `it` the stage works on byte it - delay (k_pipe: = ci)
     int lane, bpw;
     bool active;         // this lane has a block this round
     u8 *slot, *my;
@@ -464,7 +465,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
     for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
     const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
     for (; it < it_end; it++) {
-        const u32 bi = it - (u32)ci;
+        const u32 bi = it - (u32)S.delay;
 #ifdef ZPP_DEBUG_NO_COMP   // timing experiment only
         if (false) {
 #else
@@ -531,7 +532,7 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
     const u32 ht_mask = C.ht_len - 16u;
     u8 *const tbase = S.slot + C.ht_off;
     const int sizebits = C.a + 2;
-    uint2 *const st_out = reinterpret_cast<uint2 *>(lds + S.L.st_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
+    uint2 *const st_out = reinterpret_cast<uint2 *>(lds + S.L.st_off) + (size_t)ci * 2 * S.bpw + S.lane;
     const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
     const u32 total = S.total;
     InWin W;
@@ -687,19 +688,29 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
 #undef ZPH_LOAD_ROWS
 }
 
-// the weights half of an ISSE stage (see hist_loop): states from its history wave, inputs from its predecessor
-template <int NCH, bool HIO, bool IS_LAST>
+// the counter / weights half of a stage (see hist_loop): states from its history wave, an ISSE's inputs from its predecessor
+template <int NCH, bool HIO, bool IS_LAST, bool IS_ICM>
 __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
 {
     const DBatch &B = *S.B;
     const Cfg &cfg = *S.cfg;
     u8 *const lds = S.lds;
     const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
+    const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
+    auto stretch_of = [&](u32 cm) -> i32 {                              // see zpq_chain.hip
+        u32 q = cm >> 8;
+        q = min(max(q, 1u), 32767u);
+        const u32 wv = s_stretch[q >> 4];
+        const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+        const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+        const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+        return (q < 64u || q >= 32704u) ? endv : midv;
+    };
     const int ci = S.ci;
     u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
     u8 *const t8 = S.my + cfg.lds_off8[ci];
-    const uint2 *const st_in = reinterpret_cast<const uint2 *>(lds + S.L.st_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
-    const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(ci - 1) * 2 * S.bpw + S.lane;
+    const uint2 *const st_in = reinterpret_cast<const uint2 *>(lds + S.L.st_off) + (size_t)ci * 2 * S.bpw + S.lane;
+    const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(ci > 0 ? ci - 1 : 0) * 2 * S.bpw + S.lane;
     uint4 *const link_out = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)ci * 2 * S.bpw + S.lane;
     const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
     const u32 total = S.total;
@@ -715,7 +726,8 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
             const u32 cb = W.byte(pos);
             const u32 ch = (pp && bi == 0) ? 0u : cb;
             const uint2 sv = st_in[((it - 1u) & 1u) * S.bpw];
-            const uint4 v = link_in[((it - 1u) & 1u) * S.bpw];
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (!IS_ICM) v = link_in[((it - 1u) & 1u) * S.bpw];
             u32 po0 = 0, po1 = 0, po2 = 0, po3 = 0;
             // the byte's first entry; afterwards the next bit's entry is fetched before this bit's update is stored and
             // the update is forwarded in registers when the state repeats (comp_loop's bit step, the weights half)
@@ -733,18 +745,30 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
                     rAv = t32[sA];
                     rAb = (i32)(int8_t)t8[sA];
                 }
-                const i32 w0 = ((i32)(cur_v << 12)) >> 12;
-                const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
-                const u32 pw = (kb >> 1) == 0 ? v.x : ((kb >> 1) == 1 ? v.y : ((kb >> 1) == 2 ? v.z : v.w));
-                const i32 pin = (i32)(int16_t)(pw >> ((kb & 1) * 16));
-                const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);       // predictor.v:615-631
-                const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
-                const i32 err = (yk ? 32767 : 0) - sq;                             // predictor.v:776-791
-                const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
-                const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-                const u32 nv = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
-                const i32 nb = nw1 >> 12;
-                const u32 outv = IS_LAST ? (u32)sq | (yk << 15) : (u32)p;
+                u32 nv, outv;
+                i32 nb;
+                if (IS_ICM) {
+                    // p = stretch(cm >> 8), carried with the entry; cm += (y*32767 - (cm >> 8)) >> 2 (predictor.v:555-563,701-709)
+                    const u32 cmv = cur_v & 0x7FFFFFu;
+                    outv = (u32)((i32)((u32)cur_b << 9) | (i32)(cur_v >> 23));
+                    const u32 cmn = (u32)wadd((i32)cmv, ((yk ? 32767 : 0) - (i32)(cmv >> 8)) >> 2);
+                    const i32 st_new = stretch_of(cmn);
+                    nv = cmn | (((u32)st_new & 0x1FFu) << 23);
+                    nb = st_new >> 9;
+                } else {
+                    const i32 w0 = ((i32)(cur_v << 12)) >> 12;
+                    const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
+                    const u32 pw = (kb >> 1) == 0 ? v.x : ((kb >> 1) == 1 ? v.y : ((kb >> 1) == 2 ? v.z : v.w));
+                    const i32 pin = (i32)(int16_t)(pw >> ((kb & 1) * 16));
+                    const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);   // predictor.v:615-631
+                    const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+                    const i32 err = (yk ? 32767 : 0) - sq;                         // predictor.v:776-791
+                    const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
+                    const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
+                    nv = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
+                    nb = nw1 >> 12;
+                    outv = IS_LAST ? (u32)sq | (yk << 15) : (u32)p;
+                }
                 {
                     const u32 ov = (outv & 0xFFFFu) << ((kb & 1) * 16);
                     if ((kb >> 1) == 0) po0 = (kb & 1) ? (po0 | ov) : ov;
@@ -873,7 +897,7 @@ struct Coder {
 
 // NST = stages in front of the coder (= its distance in bytes from the ICM); their last one's link is its input
 template <int NST, bool HIO>
-__device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
+__device__ __forceinline__ void coder_loop_d(const StageArgs &S, Coder &X, const int delay)
 {
     u8 *const lds = S.lds;
     const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(NST - 1) * 2 * S.bpw + S.lane;
@@ -882,7 +906,7 @@ __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
     for (int phase = 0; phase < (HIO ? 2 : 1); phase++) {
     const u32 it_end = (HIO && phase == 0) ? min(S.iters, S.split) : S.iters;
     for (; it < it_end; it++) {
-        const u32 bi = it - (u32)NST;
+        const u32 bi = it - (u32)delay;
 #ifdef ZPP_DEBUG_NO_CODER   // timing experiment only
         if (false) {
 #else
@@ -912,6 +936,8 @@ __device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X)
     }
     }   // phase (the coder reads no input: nothing to wait for)
 }
+template <int NST, bool HIO>
+__device__ __forceinline__ void coder_loop(const StageArgs &S, Coder &X) { coder_loop_d<NST, HIO>(S, X, NST); }
 
 // NCH = chain length (ICM + ISSEs), MIXT = a MIX2 follows it (levels 4-5); waves: NCH [+ 1] + the coder
 template <int NCH, bool MIXT, bool SP, bool HIO>
@@ -988,7 +1014,7 @@ __global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBat
         __syncthreads();
 
         StageArgs S;
-        S.B = &B; S.cfg = &cfg; S.lds = lds; S.ci = wave; S.lane = lane; S.bpw = bpw; S.active = active;
+        S.B = &B; S.cfg = &cfg; S.lds = lds; S.ci = wave; S.delay = wave; S.lane = lane; S.bpw = bpw; S.active = active;
         S.slot = slot; S.my = my; S.L = L; S.blk = (u32)blk;
         S.src = active ? B.in + B.in_off[blk] : B.in;
         S.nin = active ? (u32)(B.in_off[blk + 1] - B.in_off[blk]) : 0u;
@@ -1026,13 +1052,14 @@ __global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBat
     }
 }
 
-// The encoder of the dense short chains (levels 1-2) with every ISSE stage split into a history wave and a weights wave
-// (hist_loop / pred_loop): 2 * NCH waves.  Wave -> role, chosen for the SIMD a wave lands on (wave w runs on SIMD w & 3):
-//   NCH = 3 (level 2): 0 hist(1) | 1 pred(1) | 2 ICM | 3 pred(2) | 4 hist(2) [SIMD 0, with hist(1)] | 5 coder [SIMD 1, with pred(1)]
-//   NCH = 2 (level 1): 0 hist(1) | 1 pred(1) | 2 ICM | 3 coder
-// In iteration `it` the ICM works on byte it, hist(c) on byte it - (c - 1), pred(c) on byte it - c, the coder on byte it - NCH.
+// The encoder of the dense short chains (levels 1-2) with every stage split into a history wave and a counter / weights
+// wave (hist_loop / pred_loop): 2 * NCH + 1 waves.  Wave -> role, chosen for the SIMD a wave lands on (wave w runs on SIMD
+// w & 3) so that no SIMD issues more than ~92 instructions per bit (one wave per stage: the ISSE's 100, the ICM's 100):
+//   NCH = 3 (level 2): 0 hist(0) | 1 hist(2) | 2 pred(1) | 3 pred(2) | 4 hist(1) [SIMD 0] | 5 pred(0) [SIMD 1] | 6 coder [SIMD 2]
+//   NCH = 2 (level 1): 0 coder | 1 hist(0) | 2 hist(1) | 3 pred(1) | 4 pred(0) [SIMD 0, with the coder]
+// In iteration `it` hist(c) works on byte it - c, pred(c) on byte it - c - 1, the coder on byte it - NCH - 1.
 template <int NCH, bool HIO>
-__global__ void __launch_bounds__(64 * 2 * NCH) k_pipe2(const DBatch B, const Cfg cfg, const PipeLds L)
+__global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, const Cfg cfg, const PipeLds L)
 {
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -1057,14 +1084,22 @@ __global__ void __launch_bounds__(64 * 2 * NCH) k_pipe2(const DBatch B, const Cf
     u8 *const my = lds + LDS_STATE + (lane_on ? lane : 0) * cfg.lds_per_block;
     u32 *const misc = reinterpret_cast<u32 *>(lds + L.misc_off);
     const int wg_slots = min(bpw, nslots - wg_slot0);
-    // role of this wave: 0 = ICM, 1 = history of component comp, 2 = weights of component comp, 3 = coder
-    int role, comp;
-    if (NCH == 3) {
-        role = wave == 2 ? 0 : (wave == 0 || wave == 4 ? 1 : (wave == 5 ? 3 : 2));
-        comp = wave == 2 ? 0 : (wave <= 1 ? 1 : 2);
-    } else {
-        role = wave == 2 ? 0 : (wave == 0 ? 1 : (wave == 3 ? 3 : 2));
-        comp = wave == 2 ? 0 : 1;
+    // role of this wave: 1 = history of component comp, 2 = counter / weights of component comp, 3 = coder
+    // (cfg.split_enc: four bits per wave, role id 0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 + c: component c whole)
+    const int rid = (int)(((u64)cfg.split_enc >> (4 * wave)) & 15u);
+    const int role = rid == 6 ? 3 : (rid >= 8 ? 0 : ((rid & 1) ? 2 : 1));
+    const int comp = rid == 6 ? 0 : (rid >= 8 ? rid - 8 : (rid >> 1));
+    // delays: a whole stage works one iteration behind its predecessor's output, a split one's weights wave too, its history
+    // wave one iteration ahead of that; split_mask bit c = component c is split
+    int dH[3] = {0, 0, 0}, dP[3] = {0, 0, 0}, dC = 0;
+    {
+        const int split_mask = (int)((cfg.split_enc >> 32) & 7u);
+        int o = -1;
+        for (int c = 0; c < NCH; c++) {
+            if ((split_mask >> c) & 1) { dP[c] = o + 1 < 1 ? 1 : o + 1; dH[c] = dP[c] - 1; o = dP[c]; }
+            else { dP[c] = o + 1; dH[c] = dP[c]; o = dP[c]; }
+        }
+        dC = o + 1;
     }
 
     for (int base = wg_slot0; base < B.nblocks; base += nslots) {
@@ -1113,15 +1148,24 @@ __global__ void __launch_bounds__(64 * 2 * NCH) k_pipe2(const DBatch B, const Cf
         S.total = active ? S.nin + ((B.flags & ZPQ_FLAG_PP) ? 1u : 0u) : 0u;
         if (wave == 0) atomicMax(misc, S.total);
         __syncthreads();
-        S.iters = *misc + (u32)NCH;
+        S.iters = *misc + (u32)dC;
         S.split = (HIO && B.gate_flag) ? (B.gate_pos > 64u ? B.gate_pos - 64u : 0u) : S.iters;
+        S.delay = dP[comp];
 
         Coder X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
-        if (role == 0) comp_loop<NCH, false, HIO, true, false, false>(S);
-        else if (role == 1) hist_loop<NCH, HIO>(S, comp - 1);
-        else if (role == 2) { if (comp == NCH - 1) pred_loop<NCH, HIO, true>(S, comp); else pred_loop<NCH, HIO, false>(S, comp); }
-        else coder_loop<NCH, HIO>(S, X);
+        if (role == 0) {
+            if (comp == 0) comp_loop<NCH, false, HIO, true, false, false>(S);
+            else if (comp == NCH - 1) comp_loop<NCH, false, HIO, false, true, false>(S);
+            else comp_loop<NCH, false, HIO, false, false, false>(S);
+        }
+        else if (role == 1) hist_loop<NCH, HIO>(S, dH[comp]);
+        else if (role == 2) {
+            if (comp == 0) pred_loop<NCH, HIO, false, true>(S, dP[comp]);
+            else if (comp == NCH - 1) pred_loop<NCH, HIO, true, false>(S, dP[comp]);
+            else pred_loop<NCH, HIO, false, false>(S, dP[comp]);
+        }
+        else coder_loop_d<NCH, HIO>(S, X, dC);
         __syncthreads();
         if (role == 3 && active) {
             X.high = X.low;                                           // encode(1, 0): mid = low, high = mid
@@ -1153,7 +1197,7 @@ static bool pipe_layout(const Cfg &cfg, int bpw, zpqp::PipeLds *L, size_t *lds_b
     L->stat_off = (int32_t)off; off += (size_t)(nch + 1) * bpw * 4;
     L->misc_off = (int32_t)off; off += 16;
     L->st_off = (int32_t)off;
-    if (cfg.split_enc) off += (size_t)(nch - 1) * 2 * bpw * 8;
+    if (cfg.split_enc) off += (size_t)nch * 2 * bpw * 8;
     *lds_bytes = off;
     return off <= 160 * 1024;
 }
@@ -1204,10 +1248,28 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     }
     const bool hio = B->gate_flag != nullptr;
     if (hio && cfg.sparse) return ZPQ_E_INTERNAL;            // (striped uploads: dense levels 1-2, see zpq_chain_has_hio)
-    // dense levels 1-2: every ISSE stage split into a history wave and a weights wave (k_pipe2); ZPQ_ENC_SPLIT=0: one wave
+    // Dense level 1: every stage split into a history wave and a counter / weights wave (k_pipe2): 136 -> 101 ms for 4096
+    // blocks.  Level 2 has seven such roles for four SIMDs; every order and every mix of split and whole stages that was
+    // tried ran at 122-137 ms against 123 for k_pipe (two waves sharing a SIMD issue slower together than the instruction
+    // counts promise), so it stays on k_pipe.  ZPQ_ENC_SPLIT=0: never split; ZPQ_ENC_SPLIT=<role ids, wave 0 first>: that
+    // order (0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 W0 | 9 W1 | a W2 = whole stages), levels 1-2.
     {
         const char *ev = getenv("ZPQ_ENC_SPLIT");
-        cfg.split_enc = (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0)) ? 1 : 0;
+        cfg.split_enc = 0;
+        if (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0 && strlen(ev) == 1)) {
+            const char *order = cfg.nch_spec == 2 ? "60231" : nullptr;
+            if (ev && strlen(ev) >= 4 && strlen(ev) <= (size_t)(2 * cfg.nch_spec + 1) && strspn(ev, "012345689a") == strlen(ev)) order = ev;
+            if (order) {
+                uint64_t v = 0;
+                int mask = 0, nw = 0;
+                for (int w = 0; order[w]; w++, nw++) {
+                    const int id = order[w] == 'a' ? 10 : order[w] - '0';
+                    v |= (uint64_t)id << (4 * w);
+                    if (id < 6) mask |= 1 << (id >> 1);
+                }
+                cfg.split_enc = (int64_t)(v | ((uint64_t)mask << 32) | ((uint64_t)nw << 40) | (1ull << 48));
+            }
+        }
     }
     cfg.blocks_per_wg = blocks_per_wg;
     zpqp::PipeLds L;
@@ -1226,7 +1288,7 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
 #define ZPP_LAUNCH2(N, HIOv)                                                                                         \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void *)zpqp::k_pipe2<N, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((zpqp::k_pipe2<N, HIOv>), dim3(nwg), dim3(64 * 2 * (N)), lds, stream, *B, cfg, L);        \
+        hipLaunchKernelGGL((zpqp::k_pipe2<N, HIOv>), dim3(nwg), dim3(64 * (int)((cfg.split_enc >> 40) & 15)), lds, stream, *B, cfg, L);  \
     } while (0)
     if (cfg.split_enc) {
         if (cfg.nch_spec == 2) { if (hio) ZPP_LAUNCH2(2, true); else ZPP_LAUNCH2(2, false); }
