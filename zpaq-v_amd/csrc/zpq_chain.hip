@@ -184,6 +184,20 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // (Dense tables without a MIX2 only: with the line store the second probe doubles tag loads and selects, and the
     //  MIX2 levels have eight tables to fetch twice -- measured slower there: level 5 505 vs 466 ms.)
     constexpr bool TWO = DEC && !SPEC && !HYP && NCH > 0 && !SP && !MIXT;
+    // Line-store decoders (levels 3-5 at scale): the two outcomes of a byte's FOURTH bit lead to neighbouring contexts, and the
+    // store places neighbouring lines in one group of four slots (see ZPQ_PREFETCH) -- so for the mid-byte boundary, and only
+    // there, both outcomes are requested when the third bit is known: one tag group and two neighbouring lines three times out
+    // of four, a whole bit step early.  (The byte boundary's two outcomes are unrelated lines: asking for both was measured
+    // slower in round 2, level 5 505 vs 466 ms.)
+    // Built in round 3, parity-green (65 GPU tests), MEASURED SLOWER at the shapes bench.py ships: level 3 x 4096 393.5 against
+    // 382.6 ms, level 4 x 4096 511.6 against 491.1, level 5 x 3072 503.0 against 477.4 -- the second set of tag and row loads,
+    // the seventeen selects and 30-60 more registers cost more than the hidden half round trip, and four neighbouring lines
+    // filling one home group push unrelated lines into the walk.  Compiled only with -DZPQ_TWOM (tools/variant.sh).
+#ifdef ZPQ_TWOM
+    constexpr bool TWOM = DEC && !SPEC && SP && NCH > 0;
+#else
+    constexpr bool TWOM = false;
+#endif
     // (Requesting only the LIKELIER outcome early -- as soon as the last bit's probability is known, asking again after
     //  a wrong guess -- was measured as well: level 3 375 -> 472 ms, level 5 467 -> 557 ms.  Every speculative row read
     //  these decoders add costs more in memory latency under load than it hides; they request after the bit is known.)
@@ -202,6 +216,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     constexpr bool SPARSE = SP;
     const u32 sp_cap = (SPARSE && hashed) ? C.sp_cap : 0u;
     const u32 sp_groups = sp_cap >> 2;
+    const u32 sp_qbits = (SPARSE && hashed && C.ht_len >= 256u) ? (u32)(31 - __clz((int)C.ht_len)) - 8u : 0u;   // log2(lines / 4)
     u32 *sp_tags = reinterpret_cast<u32 *>(slot + C.sp_tag_off);
     // every row access of this lane is tbase + a 32-bit byte offset: the dense table, or the store's line array
     // (offsets, not pointers, so that the h0 ^ 16 / ^ 32 neighbours stay provably global addresses)
@@ -431,8 +446,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         const u32 h0_ = (cx_ * 16u) & ht_mask;                                          \
         u32 pox_ = SWZ ? swz_addr(h0_) : h0_;                                           \
         if (SPARSE && sp_cap) {                                                         \
-            key_ = (h0_ >> 6) + 1u;                                                     \
-            si_ = __umulhi(key_ * 0x9E3779B1u, sp_cap);                                 \
+            /* the line's index with the two lowest bits moved to the top (neighbouring second-nibble contexts = */ \
+            /* neighbouring indices); four neighbouring indices share a home group, index & 3 is the home slot     */ \
+            const u32 tl_ = TWOM ? (((h0_ >> 6) & 3u) << sp_qbits) | (h0_ >> 8) : (h0_ >> 6); \
+            key_ = tl_ + 1u;                                                            \
+            si_ = TWOM ? 4u * __umulhi((tl_ >> 2) * 0x9E3779B1u, sp_groups) + (tl_ & 3u) : __umulhi(key_ * 0x9E3779B1u, sp_cap); \
             off_ = h0_ & 48u;                                                           \
             tags_ = *reinterpret_cast<const u32x4 *>(sp_tags + (si_ & ~3u));            \
             pox_ = (si_ << 6) + off_;                                                   \
@@ -489,7 +507,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             constexpr bool MID = decltype(midc)::value;        // the rows of a byte's second nibble
             bool claim = false;
             u32 claim_si = 0;
-            if (TWO || (HYP4 && MID)) {                        // (selects, not a branch: both requests are waited for here anyway)
+            if (TWO || ((HYP4 || TWOM) && MID)) {              // (selects, not a branch: both requests are waited for here anyway)
                 auto sel4 = [](const bool c, const u32x4 a, const u32x4 b) -> u32x4 {
                     return u32x4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
                 };
@@ -862,7 +880,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 // the nibble's last bit is known: request the next nibble's rows now, so that their
                 // latency overlaps this bit's update work (contexts: predictor.v:558-560,809-816)
                 const u32 c8n = (X.c8 << 1) | (u32)y;
-                if (bit == 4) prefetch_rows(hctx, c8n);
+                if (bit == 4) { if (TWOM) sel_alt = y != 0; else prefetch_rows(hctx, c8n); }
                 else { hnext_dec = run_vm(c8n - 256u); prefetch_rows(hnext_dec, 1u); }
             }
             if (DEC && K == 3 && TWO) {
@@ -940,6 +958,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             else { X.r3 = (X.slot & 4u) ? ins : X.r3; X.r2 = (X.slot & 4u) ? X.r2 : ins; }
             X.c8 = (X.c8 << 1) | (u32)y;
             X.slot = (K == 3) ? 1u : (X.slot * 2u + (u32)y);
+            if (TWOM && bit == 5) {
+                const u32 c8n = X.c8 << 1;                       // (mid-byte: both values of the fourth bit, see TWOM)
+                prefetch_alt(hctx, c8n | 1u);
+                prefetch_rows(hctx, c8n);
+            }
             if (TWO && K == 2) {
                 // three bits of the nibble are known: request the next nibble's rows for both values of the fourth
                 const u32 c8n = X.c8 << 1;

@@ -1243,6 +1243,7 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
         const int nslots = B->nslots;
         const int cap = cfg.blocks_per_wg;
         int per = blocks_per_wg < 16 ? (cap < 16 ? cap : 16) : blocks_per_wg;
+        { const char *ev = getenv("ZPQ_PIPE_PER"); if (ev && atoi(ev) >= 9 && atoi(ev) <= cap) per = atoi(ev); }   // experiments
         nwg = (nslots + per - 1) / per;
         blocks_per_wg = (nslots + nwg - 1) / nwg;
     }
@@ -1278,7 +1279,7 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     // A small batch has few blocks per workgroup and would fit several workgroups into one CU's LDS -- whose waves
     // would then share SIMDs while other CUs idle (measured: 1024 blocks 254 ms instead of 114).  Asking for more than
     // half of the LDS keeps it at one workgroup per CU, one wave per SIMD.
-    if (lds < 81 * 1024) lds = 81 * 1024;
+    { const char *ev = getenv("ZPQ_PIPE_SHARE"); if (!(ev && atoi(ev) == 1) && lds < 81 * 1024) lds = 81 * 1024; }
 #define ZPP_LAUNCH(N, MX, SPv, HIOv)                                                                                 \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void *)zpqp::k_pipe<N, MX, SPv, HIOv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
