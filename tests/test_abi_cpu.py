@@ -114,3 +114,30 @@ def test_encoder_choice_is_host_logic(zpq, monkeypatch):
     from inputs import C4B
     m = zpq.Model(header=C4B)
     assert not m.has_fast_path and L.zpq_pipe_applies(m.h, 8, 100) == 0
+
+
+def test_decoder_choice_is_host_logic(zpq, monkeypatch):
+    """The wave-split decoder (zpq_dpipe.hip) is opt-in -- it measured slower than the lane-per-component one -- and only
+    ever takes the dense chains of levels 1-3 from 12 resident blocks on, at most 32 per workgroup (a block is a lane pair);
+    the 'touched bitmap' decode path exists only in timing builds (zpq_dpipe_applies, zpq_chain_touch_decode: internal)."""
+    L = zpq.lib()
+    for f in (L.zpq_dpipe_applies,):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f.restype = C.c_int
+    L.zpq_chain_touch_decode.argtypes = [C.c_void_p]
+    L.zpq_chain_touch_decode.restype = C.c_int
+    L.zpq_pipe_touch.restype = C.c_int
+    monkeypatch.delenv("ZPQ_DEC_PIPE", raising=False)
+    for level in (1, 2, 3, 4, 5):
+        m = zpq.Model(level=level)
+        assert L.zpq_dpipe_applies(m.h, 16, 8192) == 0           # not asked for
+        assert L.zpq_chain_touch_decode(m.h) == 0 and L.zpq_pipe_touch() == 0
+    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")
+    for level, cap in ((1, 32), (2, 32), (3, 16)):
+        m = zpq.Model(level=level)
+        assert L.zpq_dpipe_applies(m.h, cap, 11) == 0
+        assert L.zpq_dpipe_applies(m.h, cap, 12) == 1
+        assert L.zpq_dpipe_applies(m.h, cap, 8192) == 1
+        assert L.zpq_dpipe_applies(m.h, 33, 8192) == 0
+    for level in (4, 5):                                         # a MIX2 follows the chain: the lane-per-component decoder
+        assert L.zpq_dpipe_applies(zpq.Model(level=level).h, 12, 8192) == 0

@@ -20,10 +20,15 @@ def test_specialised_kernels_use_no_scratch(zpq):
         if not runtime_loop:
             assert r["scratch"] == 0, (name, r)
         assert r["vgpr"] <= 256, (name, r)                    # two waves of one workgroup may share a SIMD
-    pipe = {k: v for k, v in t.items() if "k_pipe" in k}
+    pipe = {k: v for k, v in t.items() if "k_pipeI" in k}
     assert len(pipe) >= 8, sorted(t)                          # levels 1-3 x dense / line store (+ striped-upload forms)
     for name, r in pipe.items():
         assert r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)   # (level 3: six waves of one workgroup on four SIMDs)
+    # round 3: the level-1 encoder with split stages (k_pipe2) and the wave-split decoder (k_dpipe, opt-in)
+    extra = {k: v for k, v in t.items() if "k_pipe2" in k or "k_dpipe" in k}
+    assert len(extra) >= 7, sorted(t)
+    for name, r in extra.items():
+        assert r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
     for name, r in t.items():
         if "k_lanes" in name and name.endswith("Lb1EEEv6DBatchNS_4LCfgE"):   # the hash-chain instantiation (no interpreter)
             assert r["scratch"] == 0, (name, r)
