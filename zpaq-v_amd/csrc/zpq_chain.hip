@@ -201,8 +201,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // (Requesting only the LIKELIER outcome early -- as soon as the last bit's probability is known, asking again after
     //  a wrong guess -- was measured as well: level 3 375 -> 472 ms, level 5 467 -> 557 ms.  Every speculative row read
     //  these decoders add costs more in memory latency under load than it hides; they request after the bit is known.)
-    const int hyp = HYP ? ((li >> 2) & 1) : 0;           // the outcome this lane assumes
-    const int lc = HYP ? (li & 3) : li;                  // the component this lane works for
+    // (the two copies of a component sit on NEIGHBOURING lanes, 2c and 2c + 1: what one copy takes over from the other is
+    //  then one DPP quad_perm move per register instead of two bank-masked row shifts)
+    const int hyp = HYP ? (li & 1) : 0;                  // the outcome this lane assumes
+    const int lc = HYP ? (li >> 1) : li;                 // the component this lane works for
+    auto comp_lane = [](const int c) -> int { return HYP ? 2 * c : c; };   // lane (inside the block) of component c, copy 0
     const int ctype = (lc < n) ? M.comp[lc].type : 0;
     const bool hashed = ctype == ZT_ICM || ctype == ZT_ISSE;
     const bool is_icm = ctype == ZT_ICM, is_last = lc == last;
@@ -376,6 +379,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // decoded bit from lane `last` to the lanes below it: log-step DPP row_shl, no LDS round trip
         const int bdist = last - lc;                       // > 0 on lanes that need the value
         auto bcast_down = [&](i32 v) -> i32 {
+            if constexpr (HYP && NCH == 2) {
+                // lanes c0h0 c0h1 c1h0 c1h1 share a quad: every lane takes its own copy's coder lane (both decode the same bit)
+                return __builtin_amdgcn_update_dpp(v, v, 0xEE /*quad_perm:[2,3,2,3]*/, 0xf, 0xf, false);
+            }
+            if constexpr (HYP && NCH == 3) {
+                // the coder lanes are 4 and 5 of the block's eight: spread them over their quad, then hand the quad down
+                v = __builtin_amdgcn_update_dpp(v, v, 0x44 /*quad_perm:[0,1,0,1]*/, 0xf, 0xa, false);
+                return __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+            }
             if constexpr (NCH > 0 && NCH + (MIXT ? 1 : 0) <= 4) {
                 // all of the block's lanes are in one quad: one quad_perm broadcast of the coder lane
                 constexpr int L = NCH + (MIXT ? 1 : 0) - 1;
@@ -483,12 +495,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // the wait for the loads does not also wait for a just-issued store), then the caller
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
         // is one of the candidates.
-        // two-hypothesis decode: the same register of the block's OTHER copy (lane ^ 4): lanes 0..3 of each eight take
-        // from four lanes up, lanes 4..7 from four lanes down (bank masks 0101 / 1010 of a 16-lane DPP row)
+        // two-hypothesis decode: the same register of the block's OTHER copy (lane ^ 1)
         auto xchg = [&](const u32 v) -> u32 {
-            u32 t = (u32)__builtin_amdgcn_update_dpp((i32)v, (i32)v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
-            t = (u32)__builtin_amdgcn_update_dpp((i32)t, (i32)v, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
-            return t;
+            return (u32)__builtin_amdgcn_update_dpp((i32)v, (i32)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false);
         };
         bool row_mine = true;                              // this copy requested the rows of the nibble that really follows
         // Two-hypothesis decode, a byte's SECOND nibble: its 16 possible contexts are hctx + 16 * (16..31) (predictor.v:558-560),
@@ -501,7 +510,11 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 #ifdef ZPQ_NO_HYP4
         constexpr bool HYP4 = false;
 #else
+#ifdef ZPQ_HYP4_L1
+        constexpr bool HYP4 = HYP && SWZ;
+#else
         constexpr bool HYP4 = HYP && SWZ && NCH == 3;         // (level 1, one hashed table of 32 MiB beside a small one: measured 272 vs 269 ms)
+#endif
 #endif
         auto take_prefetched = [&](const bool have_prev, auto midc) {
             constexpr bool MID = decltype(midc)::value;        // the rows of a byte's second nibble
@@ -992,7 +1005,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             i32 p = is_icm ? cur_pst : 0, pin = 0;
 #pragma unroll
             for (int i = 1; i < (NCH ? NCH : 1); i++) {
-                const i32 pv = row_shr1(p);
+                const i32 pv = __builtin_amdgcn_update_dpp(p, p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, false);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);
                 const bool me = lc == i;
                 pin = me ? pv : pin;
@@ -1146,7 +1159,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                         X.code = (X.code << 8) | c;
                     }
                 }
-                eof = row_bcast(eof, row_base + last);
+                eof = row_bcast(eof, row_base + comp_lane(last));
                 if (eof) { stop = true; break; }
             }
 
@@ -1236,7 +1249,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             oq_flush();
         }
         i32 st0 = row_bcast(status, row_base);                 // VM status lives on lane 0
-        for (int c = 1; c < n; c++) { const i32 sc = row_bcast(status, row_base + c); st0 = st0 ? st0 : sc; }   // line-store overflow: any hashed lane
+        for (int c = 1; c < n; c++) { const i32 sc = row_bcast(status, row_base + comp_lane(c)); st0 = st0 ? st0 : sc; }   // line-store overflow: any hashed lane
         if (is_last && hyp == 0) {
             i32 st = st0;
             if (X.opos > cap && st == ZPQ_OK) st = ZPQ_E_OVERFLOW;
