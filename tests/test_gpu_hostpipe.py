@@ -110,12 +110,13 @@ def test_decode_multi_matches_single(zpq, gpu_ctx):
         other.close()
 
 
-def test_striped_upload_equals_plain_upload(zpq, gpu_ctx, monkeypatch):
-    """A single round of equally long blocks from pinned memory is uploaded in two stripes: the first 8 KiB of every block,
+@pytest.mark.parametrize("level", [2, 1])
+def test_striped_upload_equals_plain_upload(zpq, gpu_ctx, monkeypatch, level):
+    """(Level 1: the encoder with split stages, k_pipe2, in its striped-upload form.)  A single round of equally long blocks from pinned memory is uploaded in two stripes: the first 8 KiB of every block,
     then -- beside the running encoder -- the rest, with an in-kernel gate on a pinned flag.  Same streams as the plain
     upload and as the oracle; block contents differ in BOTH stripes, so a lane that read past the gate too early, or
     stale bytes, would show."""
-    model = zpq.Model(level=2)
+    model = zpq.Model(level=level)
     nb, size = 160, 40960
     blocks = [bytes(W.make_block(b, size)) for b in range(nb)]
     caps = [size + size // 8 + 1024] * nb
