@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
         for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
         u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
-        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[min(max(i - 1, 0), 4093)];   // entry p + 2048 = squash(p): no clamp in the bit loop (|p| <= 2048)
         u8 *ns = lds + LDS_NS;
         for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
     }
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
             }
             if constexpr (SKEW) pout[KB] = p;
-            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];      // squash(p[li]) (predictor.v:193-202,667)
+            const i32 sq = s_squash[p + 2048];      // squash(p[li]) (predictor.v:193-202,667)
             // ---- (3) off the critical path: the ICM's stretch for the next bit, for both
             //          outcomes, with this bit's cm update forwarded when the state repeats
             // cm += (y*32767 - (cm >> 8)) >> 2 (predictor.v:706-708).  Encode knows y and computes one outcome; the
@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 pin = me ? pv : pin;
                 p = me ? pn : p;
             }
-            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+            const i32 sq = s_squash[p + 2048];
             // ---- this copy's outcome
             const i32 yh = hyp;
             u32 sN = 0, rNv = 0;

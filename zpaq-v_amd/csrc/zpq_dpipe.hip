@@ -295,7 +295,7 @@ __device__ __forceinline__ void dcomp_loop(const StageArgs &S)
                 }
             }
             const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);     // predictor.v:615-631
-            sq = s_squash[min(max(p + 2047, 0), 4093)];
+            sq = s_squash[p + 2048];
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- (3) this lane's outcome of the bit: h
@@ -532,7 +532,7 @@ __device__ __forceinline__ void dcoder_loop(const StageArgs &S, DecState &X)
                 const uint2 cj = cin[(size_t)(j * 2 + ppar) * bpw * 2];
                 p = clamp2k((__mul24((i32)cj.x, p) + (i32)cj.y) >> 16);
             }
-            const u32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+            const u32 sq = s_squash[p + 2048];
             u32 y = 0;
             if (!dead) {
                 const u32 p16 = sq * 2u + 1u;                               // decoder.v:86
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(64 * (NCH + 1)) k_dpipe(const DBatch B, const 
         u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
         for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
         u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
-        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[min(max(i - 1, 0), 4093)];   // entry p + 2048 = squash(p): no clamp in the bit loop (|p| <= 2048)
         u8 *ns = lds + LDS_NS;
         for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
     }

@@ -406,7 +406,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
             const u32 pw = (KB >> 1) == 0 ? pi0 : ((KB >> 1) == 1 ? pi1 : ((KB >> 1) == 2 ? pi2 : pi3));
             const i32 pin = (i32)(int16_t)(pw >> ((KB & 1) * 16));
             const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);
-            const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+            const i32 sq = s_squash[p + 2048];
             const i32 err = (yk ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
@@ -761,7 +761,7 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
                     const u32 pw = (kb >> 1) == 0 ? v.x : ((kb >> 1) == 1 ? v.y : ((kb >> 1) == 2 ? v.z : v.w));
                     const i32 pin = (i32)(int16_t)(pw >> ((kb & 1) * 16));
                     const i32 p = clamp2k((__mul24(w0, pin) + (w1 << 6)) >> 16);   // predictor.v:615-631
-                    const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+                    const i32 sq = s_squash[p + 2048];
                     const i32 err = (yk ? 32767 : 0) - sq;                         // predictor.v:776-791
                     const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
                     const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
@@ -852,7 +852,7 @@ __device__ __forceinline__ void mix_loop(const StageArgs &S)
                 const i32 pk = (i32)(int16_t)(wk >> ((kb & 1) * 16)), pj = (i32)(int16_t)(wj >> ((kb & 1) * 16));
                 const i32 w = (i32)mw[kb];
                 const i32 p = clamp2k(wadd(wmul(w, pj), wmul(65536 - w, pk)) >> 16);
-                const i32 sq = s_squash[min(max(p + 2047, 0), 4093)];
+                const i32 sq = s_squash[p + 2048];
                 const i32 err = (yk ? 32767 : 0) - sq;
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 wn = wadd(w, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBat
         u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
         for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
         u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
-        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[min(max(i - 1, 0), 4093)];   // entry p + 2048 = squash(p): no clamp in the bit loop (|p| <= 2048)
         u8 *ns = lds + LDS_NS;
         for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
     }
@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, co
         u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
         for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
         u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
-        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[min(max(i - 1, 0), 4093)];   // entry p + 2048 = squash(p): no clamp in the bit loop (|p| <= 2048)
         u8 *ns = lds + LDS_NS;
         for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
     }
