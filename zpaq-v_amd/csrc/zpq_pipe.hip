@@ -136,9 +136,7 @@ struct Row {
 // ------------------------------------------------------------------ a component stage
 // IS_LAST: the component the coder follows (its link carries squash(p) and the bit).  FWD_PIN: the last ISSE of a chain
 // that a MIX2 follows: it hands its INPUT on as well (the MIX2 mixes p[n-3] and p[n-2], levels.v:199-218,290-375).
-// CI: the stage's component index when the caller knows it at compile time (-1: S.ci) -- the context hash then unrolls
-// instead of looping ci + 1 times around a quarter-rate multiply, and the component's descriptors are fixed addresses.
-template <int NCH, bool SP, bool HIO, bool IS_ICM, bool IS_LAST, bool FWD_PIN, int CI = -1>
+template <int NCH, bool SP, bool HIO, bool IS_ICM, bool IS_LAST, bool FWD_PIN>
 __device__ __forceinline__ void comp_loop(const StageArgs &S)
 {
     const DBatch &B = *S.B;
@@ -157,7 +155,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
         return (q < 64u || q >= 32704u) ? endv : midv;
     };
-    const int ci = CI >= 0 ? CI : S.ci;
+    const int ci = S.ci;
     const DComp &C = M.comp[ci];
     const u32 ht_mask = C.ht_len - 16u;
     const u32 sp_cap = SP ? C.sp_cap : 0u;
@@ -1032,9 +1030,9 @@ __global__ void __launch_bounds__(64 * (NCH + (MIXT ? 2 : 1))) k_pipe(const DBat
 
         Coder X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
-        if (wave == 0) comp_loop<NCH, SP, HIO, true, false, false, 0>(S);
-        else if (wave < NCH - 1) comp_loop<NCH, SP, HIO, false, false, false, (NCH == 3 ? 1 : -1)>(S);
-        else if (wave == NCH - 1) comp_loop<NCH, SP, HIO, false, !MIXT, MIXT, NCH - 1>(S);
+        if (wave == 0) comp_loop<NCH, SP, HIO, true, false, false>(S);
+        else if (wave < NCH - 1) comp_loop<NCH, SP, HIO, false, false, false>(S);
+        else if (wave == NCH - 1) comp_loop<NCH, SP, HIO, false, !MIXT, MIXT>(S);
         else if (MIXT && wave == NCH) mix_loop<NCH, HIO>(S);
         else coder_loop<NST, HIO>(S, X);
         __syncthreads();
