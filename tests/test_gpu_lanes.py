@@ -226,3 +226,46 @@ def test_four_blocks_per_wave_equals_one_block_per_wave(zpq, gpu_ctx, monkeypatc
     assert (status == 0).all() and one == want
     dec, status, *_ = gpu_ctx.decode_blocks(model, one, cap=8192)
     assert (status == 0).all() and dec == blocks
+
+
+def test_general_programs_ride_four_blocks_per_wave(zpq, gpu_ctx, monkeypatch):
+    """Round 3: a model with at most 16 components whose HCOMP program is NOT the shipped hash chain also rides four blocks
+    to a wave (k_rows); its program runs through the interpreter on the first lane of every row.  Random programs (every
+    opcode group incl. jumps, M and H traffic, R registers), a ragged batch whose rows end at different times, more blocks
+    than slots: identical to the one-block-per-wave kernel and to the oracle, decoded back."""
+    rnd = random.Random(2026)
+    valid = [op for op in range(256) if op not in (56, 255, 57, 58, 61, 62) and not ((op & 7) in (5, 6) and op < 56)
+             and not (120 <= op < 128) and not (240 <= op < 255)]
+    for trial in range(4):
+        prog = []
+        for _ in range(rnd.randint(8, 30)):
+            op = rnd.choice(valid)
+            prog.append(op)
+            if op & 7 == 7:
+                prog.append(rnd.choice([0, 1, 2, 3]) if op in (39, 47, 63) else
+                            rnd.choice([v for v in range(1, 255) if v not in (39, 47, 63)]))
+        prog += [112, 25, 59, 112, 56, 0]
+        header = bytes([3, 6, 0, 0, 3, 2, 12, 40, 3, 12, 8, 12, 1, 0]) + bytes(prog)
+        model = zpq.Model(header=header)
+        blocks = [bytes(W.make_block(11 * b + trial, rnd.choice([0, 1, 7, 64, 500, 1500, 3000]))) for b in range(23)]
+        want = [O.Codec(header).encode(b) for b in blocks]
+        monkeypatch.delenv("ZPQ_LANES_ROWS", raising=False)
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 7 * model.state_bytes + 100)
+        try:
+            rows, status, _ = gpu_ctx.encode_blocks(model, blocks)
+            assert gpu_ctx.last_kernel_name == "k_rows<encode>" and gpu_ctx.last_slots == 7
+            assert (status == 0).all() and rows == want
+            dec, status, *_ = gpu_ctx.decode_blocks(model, rows, cap=4096)
+            assert gpu_ctx.last_kernel_name == "k_rows<decode>" and (status == 0).all() and dec == blocks
+        finally:
+            zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+        monkeypatch.setenv("ZPQ_LANES_ROWS", "h")               # round 2's rule: only hash-chain programs ride rows
+        one, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name == "k_lanes<encode>" and (status == 0).all() and one == want
+    # a program that never halts: the step cap is a per-block status on either kernel, not a hang
+    monkeypatch.delenv("ZPQ_LANES_ROWS", raising=False)
+    loop = bytes([3, 6, 0, 0, 3, 2, 12, 40, 3, 12, 8, 12, 1, 0, 63, 0xFD, 0])   # jmp to itself: rel = ((0xFD + 128) & 255) - 127 = -2
+    model = zpq.Model(header=loop)
+    _, status, _ = gpu_ctx.encode_blocks(model, [b"abc", b"", b"x" * 40])
+    assert gpu_ctx.last_kernel_name == "k_rows<encode>"
+    assert status[0] == -8 and status[2] == -8                     # ZPQ_E_VMSTEPS (the empty block still codes the PP byte)

@@ -599,8 +599,10 @@ __device__ __forceinline__ i32 row_sum_all(i32 x, int rb)
     return __builtin_amdgcn_ds_bpermute((rb + 15) << 2, x);                  // the row's total, to every lane of the row
 }
 
-template <bool DEC>
-__global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LCfg cfg)
+// VMH as in k_lanes: true = the shipped hash chain, evaluated in registers; false = any program, through the shared
+// interpreter on lane 0 of every ROW (four interpreters per wave walking the same program on their own blocks' bytes).
+template <bool DEC, bool VMH = true>
+__global__ void __launch_bounds__(64 * WAVES, VMH ? 4 : 2) k_rows(const DBatch B, const LCfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
     const DModel &M = *B.model;
@@ -615,6 +617,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
         for (int i = tid; i < 1024; i += 64 * WAVES) dt[i] = B.dt[i];
         int16_t *d2 = reinterpret_cast<int16_t *>(lds + L_DT2K);
         for (int i = tid; i < 256; i += 64 * WAVES) d2[i] = B.dt2k[i];
+        if (!VMH) for (int i = tid; i < M.hdr_len && i < ZPQ_MAX_HDR; i += 64 * WAVES) lds[L_HDR + i] = M.header[i];
     }
     __syncthreads();
     const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + L_STRETCH);
@@ -692,6 +695,14 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
         const u32 nin = (u32)(B.in_off[blk + 1] - B.in_off[blk]);
         u8 *dst = B.out + B.out_off[blk];
         const u32 cap = (u32)(B.out_off[blk + 1] - B.out_off[blk]);
+
+        Vm z;                                                      // (!VMH) the block's ZPAQL machine: M, H, R in its slot
+        z.a = z.b = z.c = z.d = 0; z.f = 0; z.pc = 0; z.out = nullptr;
+        z.m = slot + M.m_off; z.mlen = M.mlen;
+        z.h = reinterpret_cast<u32 *>(slot + M.h_off); z.hlen = M.hlen;
+        z.r = reinterpret_cast<u32 *>(slot + M.r_off);
+        z.hdr = lds + L_HDR; z.hdr_len = M.hdr_len; z.hbegin = M.hbegin; z.hend = M.hend;
+        i32 vm_status = ZPQ_OK;
 
         u32 hctx = 0, cxt = 0, v0 = 0, v1 = 0, st = 0;
         i32 pown = 0;
@@ -991,11 +1002,17 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
                 else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
             }
             const u32 byte = c8 - 256;
-            {   // H[k] = hash^(k+1)(byte, previous byte): every lane walks the chain and keeps its own link
+            if (VMH) {  // H[k] = hash^(k+1)(byte, previous byte): every lane walks the chain and keeps its own link
                 u32 a = byte, hv = 0;
                 for (int k = 0; k < cfg.vm_hashes; k++) { a = (a + vm_prev + 512u) * 773u; hv = (k == li) ? a : hv; }
                 vm_prev = byte;
                 if (act) hctx = hv;
+            } else {    // ZPAQL.run(byte); h[i] = z.h[i] (predictor.v:809-816), one interpreter per row
+                if (li == 0) { if (!vm_run(z, byte)) vm_status = ZPQ_E_VMSTEPS; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (act && (u32)li < M.hlen) hctx = z.h[li];
             }
             hmap4 = 1; c8 = 1;
 
@@ -1017,9 +1034,10 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_rows(const DBatch B, const LC
             }
             for (int sft = 24; sft >= 0; sft -= 8) { if (opos < cap) dst[opos] = (u8)(high >> sft); opos++; }
         }
+        const i32 vm_st = VMH ? (i32)ZPQ_OK : rowget(vm_status, 0);   // (the interpreter's step cap: lane 0 of the row)
         if (li == last) {
-            i32 stt = ZPQ_OK;
-            if (opos > cap) stt = ZPQ_E_OVERFLOW;
+            i32 stt = vm_st;
+            if (opos > cap && stt == ZPQ_OK) stt = ZPQ_E_OVERFLOW;
             B.out_len[blk] = opos;
             B.status[blk] = stt;
             if (DEC) {
@@ -1061,12 +1079,14 @@ extern "C" int zpq_lanes_supported(const DModel *M)
     return lanes_cfg(M, &cfg) ? 1 : 0;
 }
 
-// four blocks per wave (k_rows) when the model fits a 16-lane row and its program is the shipped hash chain
+// four blocks per wave (k_rows) when the model fits a 16-lane row; its program is evaluated in registers when it is the
+// shipped hash chain and runs through the interpreter on the row's first lane otherwise (round 3)
 static bool rows_ok(const zpql::LCfg &cfg)
 {
     const char *ev = getenv("ZPQ_LANES_ROWS");                    // tuning / test knob: "0" keeps one block per wave
-    if (ev && ev[0] == '0') return false;
-    return cfg.n <= zpql::RL && cfg.vm_hashes > 0;
+    if (ev && ev[0] == '0') return false;                         // ("h": only hash-chain programs, as in round 2)
+    if (ev && ev[0] == 'h' && cfg.vm_hashes <= 0) return false;
+    return cfg.n <= zpql::RL;
 }
 
 extern "C" int zpq_lanes_blocks_per_cu(const DModel *M)
@@ -1074,7 +1094,7 @@ extern "C" int zpq_lanes_blocks_per_cu(const DModel *M)
     zpql::LCfg cfg;
     const bool rows = lanes_cfg(M, &cfg) && rows_ok(cfg);
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rows ? (const void *)zpql::k_rows<false> : (const void *)zpql::k_lanes<false, false>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rows ? (cfg.vm_hashes > 0 ? (const void *)zpql::k_rows<false, true> : (const void *)zpql::k_rows<false, false>) : (const void *)zpql::k_lanes<false, false>,
                                                      64 * zpql::WAVES, zpql::LDS_TOTAL) != hipSuccess || nb < 1)
         nb = 2;
     return nb * zpql::WAVES * (rows ? zpql::RPW : 1);
@@ -1094,8 +1114,13 @@ extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode
     if (rows_ok(cfg)) {
         const int per_wg = zpql::WAVES * zpql::RPW;
         const dim3 g((nslots + per_wg - 1) / per_wg), t(64 * zpql::WAVES);
-        if (decode) hipLaunchKernelGGL((zpql::k_rows<true>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
-        else hipLaunchKernelGGL((zpql::k_rows<false>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+        if (cfg.vm_hashes > 0) {
+            if (decode) hipLaunchKernelGGL((zpql::k_rows<true, true>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+            else hipLaunchKernelGGL((zpql::k_rows<false, true>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+        } else {
+            if (decode) hipLaunchKernelGGL((zpql::k_rows<true, false>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+            else hipLaunchKernelGGL((zpql::k_rows<false, false>), g, t, zpql::LDS_TOTAL, stream, *B, cfg);
+        }
         return ZPQ_OK;
     }
     const int grid = (nslots + zpql::WAVES - 1) / zpql::WAVES;
