@@ -141,3 +141,31 @@ def test_decoder_choice_is_host_logic(zpq, monkeypatch):
         assert L.zpq_dpipe_applies(m.h, 33, 8192) == 0
     for level in (4, 5):                                         # a MIX2 follows the chain: the lane-per-component decoder
         assert L.zpq_dpipe_applies(zpq.Model(level=level).h, 12, 8192) == 0
+
+
+def test_which_general_models_the_wave_pipeline_encodes(zpq, monkeypatch):
+    """Host logic (zpq_gpipe_applies, internal): the wave-per-component encoder takes a general model when its program is the
+    shipped hash chain, it has at most 15 components and every input names an EARLIER component (a MIX: at most eight)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from inputs import C4B
+    from test_gpu_gpipe import LEFT, TAKEN
+    from test_gpu_lanes import MODELS, hdr
+    L = zpq.lib()
+    L.zpq_gpipe_applies.argtypes = [C.c_void_p]
+    L.zpq_gpipe_applies.restype = C.c_int
+    monkeypatch.delenv("ZPQ_ENC_GPIPE", raising=False)
+    assert sorted(TAKEN + LEFT) == sorted(MODELS)
+    for name in TAKEN:
+        assert L.zpq_gpipe_applies(zpq.Model(header=hdr(MODELS[name])).h) == 1, name
+    for name in LEFT:
+        assert L.zpq_gpipe_applies(zpq.Model(header=hdr(MODELS[name])).h) == 0, name
+    assert L.zpq_gpipe_applies(zpq.Model(header=C4B).h) == 1
+    for level in range(1, 6):                                    # (level 1's program is not the hash chain)
+        assert L.zpq_gpipe_applies(zpq.Model(level=level).h) == (1 if level >= 2 else 0)
+    # a MIX over more than eight inputs, more than 15 components, a program that is not the hash chain
+    assert L.zpq_gpipe_applies(zpq.Model(header=hdr([[3, 12]] + [[8, 12, i] for i in range(9)] + [[7, 4, 0, 10, 16, 255]])).h) == 0
+    assert L.zpq_gpipe_applies(zpq.Model(header=hdr([[3, 12]] + [[8, 12, i] for i in range(15)])).h) == 0
+    other = bytes([3, 6, 0, 0, 3, 2, 12, 40, 3, 12, 8, 12, 1, 0]) + bytes([112, 25, 59, 112, 56, 0])
+    assert L.zpq_gpipe_applies(zpq.Model(header=other).h) == 0
+    monkeypatch.setenv("ZPQ_ENC_GPIPE", "0")
+    assert L.zpq_gpipe_applies(zpq.Model(header=C4B).h) == 0

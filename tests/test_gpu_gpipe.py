@@ -1,0 +1,96 @@
+"""GPU parity: the wave-per-component ENCODER of general models (k_gpipe, zpq_gpipe.hip: wave = component, lane = block,
+predictions handed from wave to wave through LDS rings) against the CPU oracle and against the lane-per-component encoder
+(k_rows / k_lanes) on the same batches.  Decoding stays with k_rows / k_lanes: every batch is decoded back."""
+import os
+import random
+import sys
+
+import pytest
+
+import oracle_lib as O
+import workload as W
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from inputs import C4B, INPUTS  # noqa: E402
+from test_gpu_lanes import MODELS, hdr  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# which of test_gpu_lanes' models the pipeline takes: all nine types, inputs that are EARLIER components only
+TAKEN = ["const", "cm", "cm_small_limit", "match", "matchonly", "avg", "mix2", "mix2_mask0", "isse", "mix", "sse", "sse_out_of_table"]
+LEFT = ["avg_bad_index", "isse_stale_input", "isse_no_input", "mix_over_range", "unknown_type",
+        "fwd_avg", "fwd_isse", "fwd_mix_self", "fwd_sse_self", "fwd_mix2", "fwd_chain"]
+
+
+def both_encoders(zpq, ctx, model, blocks, flags, cap=None):
+    pipe, st1, len1 = ctx.encode_blocks(model, blocks, flags=flags, cap=cap)
+    name = ctx.last_kernel_name
+    os.environ["ZPQ_ENC_GPIPE"] = "0"
+    try:
+        rows, st2, len2 = ctx.encode_blocks(model, blocks, flags=flags, cap=cap)
+        other = ctx.last_kernel_name
+    finally:
+        del os.environ["ZPQ_ENC_GPIPE"]
+    return name, pipe, st1, len1, other, rows, st2, len2
+
+
+@pytest.mark.parametrize("name", TAKEN)
+def test_every_component_type_alone(zpq, gpu_ctx, name):
+    header = hdr(MODELS[name])
+    model = zpq.Model(header=header)
+    blocks = [INPUTS["lcg4k"], INPUTS["text2k"], INPUTS["zeros256"], b"", b"a", bytes(W.make_block(3, 3000)), bytes(W.make_block(2, 1500))]
+    for flags in (zpq.FLAG_PP | zpq.FLAG_LANES, zpq.FLAG_LANES):
+        pp = bool(flags & zpq.FLAG_PP)
+        name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, flags)
+        assert name_ == "k_gpipe<encode>" and other in ("k_rows<encode>", "k_lanes<encode>")
+        assert (st1 == 0).all() and (st2 == 0).all()
+        want = [O.Codec(header).encode(b, pp=pp) for b in blocks]
+        assert rows == want
+        assert pipe == want
+        dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, pipe, cap=4200, flags=flags)
+        assert (status == 0).all() and dec == blocks
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5])
+def test_shipped_levels(zpq, gpu_ctx, level):
+    model = zpq.Model(level=level)
+    rnd = random.Random(level)
+    blocks = [bytes(W.make_block(5 * b + level, rnd.choice([0, 1, 9, 300, 2000, 5000]))) for b in range(9)]
+    F = zpq.FLAG_PP | zpq.FLAG_LANES
+    name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, F)
+    assert name_ == "k_gpipe<encode>" and (st1 == 0).all()
+    assert pipe == [O.Codec(O.level_header(level)).encode(b) for b in blocks] == rows
+
+
+def test_all_nine_types_ragged_batch_slot_reuse_and_overflow(zpq, gpu_ctx):
+    """More blocks than a workgroup's 64 lanes, lanes that end at different bytes, fewer slots than blocks (a lane codes
+    several blocks in turn, the workgroup re-initialises its slots between rounds), an output buffer that is too small."""
+    model = zpq.Model(header=C4B)
+    rnd = random.Random(77)
+    blocks = [bytes(W.make_block(13 * b + 5, rnd.choice([0, 1, 2, 33, 255, 256, 257, 1000, 2600, 7000]))) for b in range(150)]
+    want = [O.Codec(C4B).encode(b) for b in blocks]
+    name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, zpq.FLAG_PP)
+    assert name_ == "k_gpipe<encode>" and other == "k_rows<encode>" and (st1 == 0).all() and (st2 == 0).all()
+    assert pipe == want and rows == want
+    zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 70 * model.state_bytes + 100)
+    try:
+        reuse, status, _ = gpu_ctx.encode_blocks(model, blocks)
+        assert gpu_ctx.last_kernel_name == "k_gpipe<encode>" and gpu_ctx.last_slots == 70
+        assert (status == 0).all() and reuse == want
+    finally:
+        zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+    small = [INPUTS["lcg4k"], b"abc", INPUTS["text2k"]]
+    _, status, out_len = gpu_ctx.encode_blocks(model, small, cap=64)
+    assert gpu_ctx.last_kernel_name == "k_gpipe<encode>"
+    assert list(status) == [-7, 0, -7] and [int(x) for x in out_len] == [len(O.Codec(C4B).encode(b)) for b in small]
+
+
+def test_long_input_distances_need_a_deeper_ring(zpq, gpu_ctx):
+    """A final MIX2 / SSE that names component 0 from position 13: predictions live 13 bytes in the ring."""
+    comps = [[3, 12], [2, 12, 60]] + [[8, 12, i] for i in range(1, 11)] + [[6, 6, 0, 11, 20, 255], [9, 6, 0, 20, 200]]
+    header = hdr(comps)
+    model = zpq.Model(header=header)
+    blocks = [INPUTS["lcg4k"][:1800], INPUTS["text2k"], bytes(300), b""]
+    name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, zpq.FLAG_PP)
+    assert name_ == "k_gpipe<encode>" and (st1 == 0).all()
+    assert pipe == [O.Codec(header).encode(b) for b in blocks] == rows

@@ -69,10 +69,18 @@ def run_parity(zpq, ctx, header, blocks, cap=None):
     model = zpq.Model(header=header, offsets=offs)
     F = zpq.FLAG_PP | zpq.FLAG_LANES
     coded, status, _ = ctx.encode_blocks(model, blocks, cap=cap, flags=F)
-    assert ctx.last_kernel_name in ("k_lanes<encode>", "k_rows<encode>")     # (k_rows: n <= 16 and the hash-chain program)
+    # k_rows: n <= 16; k_gpipe (wave per component): hash-chain program and every input an earlier component
+    assert ctx.last_kernel_name in ("k_lanes<encode>", "k_rows<encode>", "k_gpipe<encode>")
     assert (status == 0).all(), status
     want = [O.Codec(header, offs).encode(b) for b in blocks]
     assert coded == want
+    if ctx.last_kernel_name == "k_gpipe<encode>":        # the lane-per-component encoder stays covered
+        os.environ["ZPQ_ENC_GPIPE"] = "0"
+        try:
+            other, status, _ = ctx.encode_blocks(model, blocks, cap=cap, flags=F)
+        finally:
+            del os.environ["ZPQ_ENC_GPIPE"]
+        assert ctx.last_kernel_name in ("k_lanes<encode>", "k_rows<encode>") and (status == 0).all() and other == want
     dec, status, consumed, _, first = ctx.decode_blocks(model, coded, cap=max(len(b) for b in blocks) + 16, flags=F)
     assert ctx.last_kernel_name in ("k_lanes<decode>", "k_rows<decode>")
     assert (status == 0).all() and dec == blocks and (first == 0).all()
@@ -91,7 +99,7 @@ def test_c4b_golden_streams(zpq, gpu_ctx):
         ks = [k for k in sorted(G["streams"]) if k.startswith("c4b/") and k.endswith(mode)]
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=zpq.FLAG_PP if mode == "pp" else 0)
-        assert gpu_ctx.last_kernel_name == "k_rows<encode>" and (status == 0).all()
+        assert gpu_ctx.last_kernel_name == "k_gpipe<encode>" and (status == 0).all()
         for k, c in zip(ks, coded):
             assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k
         dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=8192, flags=zpq.FLAG_PP if mode == "pp" else 0)
@@ -184,7 +192,7 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx, nb):
     torch.cuda.synchronize()                             # order torch's fills before the ctx stream's kernels
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
-    assert gpu_ctx.last_kernel_name == "k_rows<encode>"
+    assert gpu_ctx.last_kernel_name == "k_gpipe<encode>"
     if nb == 16384:
         assert gpu_ctx.last_slots == min(nb, gpu_ctx.resident_capacity(model)) >= 8192
     gpu_ctx.decode_blocks_dev(model, nb, d_out.data_ptr(), out_off.data_ptr(), zpq.FLAG_PP, d_dec.data_ptr(),
@@ -205,6 +213,7 @@ def test_four_blocks_per_wave_equals_one_block_per_wave(zpq, gpu_ctx, monkeypatc
     16-lane row); the one-block-per-wave kernel stays for everything else.  Same model, same blocks, both kernels:
     identical streams, equal to the oracle; a ragged batch so that rows of one wave end at different times, more blocks
     than one workgroup holds, and a budget that makes rows reuse their slots."""
+    monkeypatch.setenv("ZPQ_ENC_GPIPE", "0")             # (the encoder under test here is k_rows, not the wave pipeline)
     model = zpq.Model(header=C4B)
     rnd = random.Random(16)
     blocks = [bytes(W.make_block(7 * b + 1, rnd.choice([0, 1, 5, 64, 700, 2500, 6000]))) for b in range(41)]

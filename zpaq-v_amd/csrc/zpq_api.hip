@@ -32,6 +32,10 @@ extern "C" int zpq_lanes_supported(const DModel *M);
 extern "C" int zpq_lanes_blocks_per_cu(const DModel *M);
 extern "C" int zpq_launch_lanes(const DBatch *B, const DModel *hostM, int decode, int nslots, hipStream_t stream);
 extern "C" const char *zpq_lanes_kernel_name(const DModel *M, int decode);   // k_rows (four blocks per wave) or k_lanes
+// zpq_gpipe.hip: the ENCODER of general models as a pipeline of waves (wave = component, lane = block)
+extern "C" int zpq_gpipe_applies(const DModel *M);
+extern "C" int zpq_gpipe_blocks_per_cu(const DModel *M);
+extern "C" int zpq_launch_gpipe(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream);
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
@@ -314,6 +318,7 @@ struct BatchArgs {
 // What a batch call will launch: kernel family, slot layout, resident slots and grid.
 struct Plan {
     bool chain = false, lanes = false;
+    bool gpipe = false;          // lanes family, encode: the wave-per-component pipeline (zpq_gpipe.hip)
     bool touch = false;          // dense tables that are not cleared: "touched" bitmaps (zpq_touch_layout)
     uint32_t sp = 0;             // compact line store capacity (lines), 0 = dense tables
     const DModel *M = nullptr;   // layout the kernels see (dense or compact)
@@ -398,7 +403,8 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
         const uint64_t max_by_mem = M.slot_bytes ? (c->budget / M.slot_bytes) : (uint64_t)nblocks;
         if (max_by_mem == 0 && !own_slot) return ZPQ_E_NOMEM;
         nslots = nblocks;
-        const int cap_res = c->cus * (P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
+        P->gpipe = P->lanes && !decode && zpq_gpipe_applies(&M) != 0;
+        const int cap_res = c->cus * (P->gpipe ? zpq_gpipe_blocks_per_cu(&M) : P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
         if (nslots > cap_res) nslots = cap_res;
         if (!own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
         grid = nslots;
@@ -411,9 +417,12 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
 extern "C" int zpq_ctx_resident_capacity(zpq_ctx *c, const zpq_model *m, uint32_t flags)
 {
     if (!c || !m) return ZPQ_E_ARG;
-    Plan P;
-    const int rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &P);
-    return rc != ZPQ_OK ? rc : P.nslots;
+    // the largest batch that both directions code in ONE round (a general model's encoder -- a wave per component -- holds more
+    // blocks per CU than its decoder)
+    Plan P, Q;
+    int rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &P, 0);
+    if (rc == ZPQ_OK) rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &Q, 1);
+    return rc != ZPQ_OK ? rc : (P.nslots < Q.nslots ? P.nslots : Q.nslots);
 }
 
 static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs &a)
@@ -466,6 +475,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         rc = zpq_launch_chain(&B, &M, decode, grid, bpw, c->stream, &name);
         if (rc != ZPQ_OK) return rc;
         c->last_name = name;
+    } else if (want_lanes && P.gpipe) {
+        rc = zpq_launch_gpipe(&B, &M, nslots, c->stream);
+        if (rc != ZPQ_OK) return rc;
+        c->last_name = "k_gpipe<encode>";
     } else if (want_lanes) {
         rc = zpq_launch_lanes(&B, &M, decode, nslots, c->stream);
         if (rc != ZPQ_OK) return rc;
