@@ -484,7 +484,7 @@ def main():
             run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
                     z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None, pcie=True)
             run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 64 KiB blocks at resident "
-                                          "capacity (four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
+                                          "capacity (encode: a wave per component, lane = block; decode: four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
             res["secondary"] = secondary
 
         for _name, _fn in (("per_class", _per_class), ("incl_pcie", _incl_pcie), ("secondary", _secondary)):

@@ -25,6 +25,13 @@ LEFT = ["avg_bad_index", "isse_stale_input", "isse_no_input", "mix_over_range", 
 def both_encoders(zpq, ctx, model, blocks, flags, cap=None):
     pipe, st1, len1 = ctx.encode_blocks(model, blocks, flags=flags, cap=cap)
     name = ctx.last_kernel_name
+    os.environ["ZPQ_GPIPE_BATCH"] = "0"                  # the pipeline's bit-serial stages (one table access per bit, in bit order)
+    try:
+        serial, st0, len0 = ctx.encode_blocks(model, blocks, flags=flags, cap=cap)
+        assert ctx.last_kernel_name == name
+    finally:
+        del os.environ["ZPQ_GPIPE_BATCH"]
+    assert serial == pipe and list(st0) == list(st1) and list(len0) == list(len1)
     os.environ["ZPQ_ENC_GPIPE"] = "0"
     try:
         rows, st2, len2 = ctx.encode_blocks(model, blocks, flags=flags, cap=cap)

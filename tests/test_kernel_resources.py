@@ -29,6 +29,11 @@ def test_specialised_kernels_use_no_scratch(zpq):
     assert len(extra) >= 7, sorted(t)
     for name, r in extra.items():
         assert r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
+    # round 3: the wave-per-component encoder of general models: up to sixteen waves of ONE workgroup, four per SIMD
+    gp = {k: v for k, v in t.items() if "k_gpipe" in k}
+    assert len(gp) == 2, sorted(t)                            # byte-batched table accesses / bit-serial stages
+    for name, r in gp.items():
+        assert r["vgpr"] <= 128 and r["scratch"] <= 16, (name, r)   # (batched: two registers spilled once per byte, measured harmless)
     for name, r in t.items():
         if "k_lanes" in name and name.endswith("Lb1EEEv6DBatchNS_4LCfgE"):   # the hash-chain instantiation (no interpreter)
             assert r["scratch"] == 0, (name, r)

@@ -13,10 +13,17 @@
 //     last component's, squashes and codes;
 //   * one s_barrier per byte keeps the waves in step.
 // A wave issues only its own type's instructions, for 64 blocks at once.  Component state lives in the block's HBM slot
-// exactly as zpq_lanes.hip lays it out (zpq_model.cpp); every table access is a per-lane load / store in program order
-// (a lane touches only its own block's tables, so the order of the reference's reads and writes is the lane's own).
+// exactly as zpq_lanes.hip lays it out (zpq_model.cpp); a lane touches only its own block's tables, so the order of the
+// reference's reads and writes is the lane's own program order.  An encoder knows all eight bits of a byte when the byte
+// starts, so a stage sends the byte's table loads out together and runs the eight predict + update steps on registers
+// (comp_stage<TYPE, BATCH = true>; BATCH = false keeps one access per bit, in bit order -- ZPQ_GPIPE_BATCH=0, tests compare).
 // The HCOMP program must be the shipped hash chain (contexts in registers); coded bytes are identical to zpq_lanes.hip's,
 // zpq_generic.hip's and the CPU oracle's.
+//
+// Measured on C4b (all nine types, 16 384 x 64 KiB blocks, MI355X): 1.40-1.46 s against k_rows<encode>'s 2.83 s.  The stage
+// that sets the pace is the MIX over seven inputs; FETCH_SIZE + WRITE_SIZE = 2.15 + 1.60 TB per launch = 31 + 23 random
+// 64-byte lines per input byte (profiles/r03_gpipe_*.txt): the model's tables do not fit any cache at this residency, and
+// the kernel runs at ~41 G random lines/s.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,6 +40,10 @@ typedef uint64_t u64;
 typedef uint8_t u8;
 typedef uint16_t u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// vector accesses that are only word-aligned (a MIX row, an SSE pair)
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+typedef unsigned int u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr int BPW = 64;                          // blocks per workgroup: lane = block
 constexpr int L_STRETCH = 0;                     // u32[2048+128]
@@ -40,7 +51,8 @@ constexpr int L_SQUASH = (2048 + 128) * 4;       // u16[4096]
 constexpr int L_NS = L_SQUASH + 4096 * 2;        // u8[1024]
 constexpr int L_DT = L_NS + 1024;                // u32[1024]
 constexpr int L_DT2K = L_DT + 4096;              // i16[256]
-constexpr int L_LINK = L_DT2K + 512;             // uint4 link[n][D][BPW], then u32 misc
+constexpr int L_BYTES = L_DT2K + 512;            // u8 bytes[16][BPW]: the input bytes, published by wave 0 for the waves behind it
+constexpr int L_LINK = L_BYTES + 16 * BPW;       // uint4 link[ring][BPW], then u32 misc
 
 struct GCfg {
     int32_t n;
@@ -48,7 +60,6 @@ struct GCfg {
     uint16_t roff[16];           // component j's ring starts here ...
     uint16_t rmask[16];          // ... and keeps rmask[j] + 1 bytes: a power of two > the distance to its farthest consumer
     int32_t hashes;              // links of the HCOMP hash chain: H[i], i >= hashes, stays 0
-    uint32_t types;              // bit t: some component has type t
 };
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
@@ -69,6 +80,7 @@ struct Stage {
     u8 *lds;
     int ci, lane, n, hashes;
     const GCfg *cfg;
+    u64 busy;                    // (-DZPG_PROF) cycles between barriers
     bool active;
     u8 *slot;
     const u8 *src;
@@ -95,7 +107,7 @@ struct P8 {
 
 // One component wave.  The per-bit code is the reference's predict() + update() for this component's type, restated on
 // the block's tables in HBM (predictor.v:536-824; the CPU oracle's pred_predict / pred_update are the same text).
-template <int TYPE>
+template <int TYPE, bool BATCH>
 __device__ __forceinline__ void comp_stage(const Stage &S)
 {
     const DBatch &B = *S.B;
@@ -136,35 +148,296 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
     // MATCH state: a = len, b = offset, c = predicted bit, cxt = bit position, limit = buffer position; Predictor.init leaves
     // sizebits / bufbits in a / b (quirk Q17, predictor.v:372-373)
     i32 ma = (TYPE == ZT_MATCH) ? ca : 0, mb = (TYPE == ZT_MATCH) ? cb : 0, mc = 0, mlimit = 0;
-    u32 mcxt = 0;
+    u32 mcxt = 0, mpred = 0;
     u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;               // ICM / ISSE: the nibble's bit-history row
     u32 roff = 0;
-    (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mcxt; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
+    (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mcxt; (void)mpred; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
 
-    auto byte_at = [&](const u32 bi) -> u32 {
-        const u32 pos = pp ? (bi ? bi - 1u : 0u) : bi;
-        const u32 v = (bi < total) ? (u32)S.src[pos] : 0u;
-        return (pp && bi == 0) ? 0u : v;
-    };
-    u32 ch_next = S.active ? byte_at(0) : 0u;
+    // Input bytes: wave 0 reads them from HBM -- one aligned dword per four bytes, the next one requested a byte early -- and
+    // leaves each in an LDS ring for the waves behind it (wave i reads byte it - i, written i iterations ago).
+    u8 *const s_bytes = lds + L_BYTES;
+    auto src_addr = [&](const u32 bi) -> uintptr_t { return reinterpret_cast<uintptr_t>(S.src) + (pp ? (bi ? bi - 1u : 0u) : bi); };
+    // BATCH: an encoder knows all eight bits of a byte, so every table address of the byte is known when the byte starts (a
+    // bit-history row's states once the row is in).  The byte's loads go out together, the eight predict + update steps then
+    // run on registers -- a value that an earlier bit of the byte already rewrote is taken from that bit, not from the load --
+    // and the stores follow in bit order.  One or two memory round trips per byte instead of eight to ten (measured: a
+    // dependent load -> store step costs ~4250 cycles in this kernel).  CONST and AVG touch no memory; a bit-history table
+    // of fewer than 8192 bytes may hold both nibbles' rows in one line and keeps the bit-serial code.
+    const bool batched = BATCH && TYPE != ZT_CONST && TYPE != ZT_AVG && !((TYPE == ZT_ICM || TYPE == ZT_ISSE) && ht_len < 8192u);
+    u32 w_cur = 0;
+    if (ci == 0 && S.active && S.nin) w_cur = *reinterpret_cast<const u32 *>(src_addr(0) & ~(uintptr_t)3);
 
     for (u32 it = 0; it < S.iters; it++) {
         const u32 bi = it - (u32)ci;
+#ifdef ZPG_PROF
+        const u64 t_in = __builtin_readcyclecounter();
+#endif
         if (S.active && bi < total) {
-            const u32 ch = ch_next;
-            ch_next = byte_at(bi + 1u);                // on its way while this byte is coded
+            u32 ch;
+            if (ci == 0) {
+                const uintptr_t a = src_addr(bi), a1 = src_addr(bi + 1u);
+                ch = (pp && bi == 0) ? 0u : (w_cur >> (8u * (u32)(a & 3))) & 255u;
+                if (bi + 1u < total && (a1 & ~(uintptr_t)3) != (a & ~(uintptr_t)3)) w_cur = *reinterpret_cast<const u32 *>(a1 & ~(uintptr_t)3);
+                s_bytes[(bi & 15u) * BPW + S.lane] = (u8)ch;
+            } else ch = s_bytes[(bi & 15u) * BPW + S.lane];
             // inputs: the predictions of this byte by the components this one names (all earlier ones)
             P8 in0 = {0, 0, 0, 0}, in1 = {0, 0, 0, 0};
             P8 inm[8];
             if (TYPE == ZT_AVG) { in0 = ring_get(ca, bi); in1 = ring_get(cb, bi); }
             else if (TYPE == ZT_MIX2) { in0 = ring_get(cj, bi); in1 = ring_get(ck, bi); }
             else if (TYPE == ZT_ISSE || TYPE == ZT_SSE) in0 = ring_get(cb, bi);
-            else if (TYPE == ZT_MIX) {
+            else if (TYPE == ZT_MIX && !batched) {
 #pragma unroll
                 for (int l = 0; l < 8; l++) inm[l] = l < climit ? ring_get(cb + l, bi) : P8{0, 0, 0, 0};
             }
             (void)in0; (void)in1; (void)inm;
             P8 out = {0, 0, 0, 0};
+            if (batched) {
+                // the byte's bit contexts (predictor.v:807-823), all eight up front
+                u32 c8a[8], hma[8];
+                i32 ya[8];
+                {
+                    u32 c8 = 1, hm = 1;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const u32 y = (ch >> (7 - k)) & 1u;
+                        c8a[k] = c8; hma[k] = hm; ya[k] = (i32)y;
+                        c8 = (c8 << 1) | y;
+                        if (k == 3) hm = ((hm & 0xfu) << 5) | (y << 4) | 1u;
+                        else hm = (hm & 0x1f0u) | (((hm & 0xfu) * 2u + y) & 0xfu);
+                    }
+                }
+                if (TYPE == ZT_CM) {                             // predictor.v:549-554,681-700
+                    u32 idx[8], v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { idx[k] = (hctx ^ hma[k]) & (cm_len - 1u); v[k] = cm[idx[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        u32 pn = v[k];
+#pragma unroll
+                        for (int j = 0; j < k; j++) pn = idx[j] == idx[k] ? v[j] : pn;
+                        out.set(k, stretch((i32)(pn >> 17)));
+                        const i32 count = (i32)(pn & 0x3ffu);
+                        const i32 err = (ya[k] ? 32767 : 0) - (i32)(pn >> 17);
+                        const i32 upd = wmul(err, (i32)s_dt[count]) & -1024;
+                        v[k] = (u32)wadd(wadd((i32)pn, upd), count < climit ? 1 : 0);
+                        cm[idx[k]] = v[k];
+                    }
+                } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {  // predictor.v:495-532,555-563,615-631,701-709,776-791
+                    u32 R[2][4], ro[2];
+                    {
+                        u32x4 A[2], Bq[2], Cq[2];
+                        u32 chk[2], h0[2];
+#pragma unroll
+                        for (int nb = 0; nb < 2; nb++) {
+                            const u32 cx = hctx + 16u * c8a[4 * nb];
+                            chk[nb] = (cx >> (ca + 2)) & 255u;
+                            h0[nb] = (cx * 16u) & (ht_len - 16u);
+                            A[nb] = *reinterpret_cast<const u32x4 *>(ht + h0[nb]);
+                            Bq[nb] = *reinterpret_cast<const u32x4 *>(ht + (h0[nb] ^ 16u));
+                            Cq[nb] = *reinterpret_cast<const u32x4 *>(ht + (h0[nb] ^ 32u));
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < 2; nb++) {
+                            const bool ma_ = (A[nb].x & 255u) == chk[nb], mb_ = (Bq[nb].x & 255u) == chk[nb], mc_ = (Cq[nb].x & 255u) == chk[nb];
+                            const u32 qa = (A[nb].x >> 8) & 255u, qb = (Bq[nb].x >> 8) & 255u, qc = (Cq[nb].x >> 8) & 255u;
+                            const bool va = qa <= qb && qa <= qc, vb = qb < qc;
+                            const bool hit = ma_ || mb_ || mc_;
+                            const bool ua = ma_ || (!hit && va);
+                            const bool ub = !ua && (mb_ || (!hit && vb));
+                            ro[nb] = ua ? h0[nb] : (ub ? (h0[nb] ^ 16u) : (h0[nb] ^ 32u));
+                            R[nb][0] = hit ? (ua ? A[nb].x : (ub ? Bq[nb].x : Cq[nb].x)) : chk[nb];
+                            R[nb][1] = hit ? (ua ? A[nb].y : (ub ? Bq[nb].y : Cq[nb].y)) : 0u;
+                            R[nb][2] = hit ? (ua ? A[nb].z : (ub ? Bq[nb].z : Cq[nb].z)) : 0u;
+                            R[nb][3] = hit ? (ua ? A[nb].w : (ub ? Bq[nb].w : Cq[nb].w)) : 0u;
+                        }
+                    }
+                    // the eight states: a bit reads a slot of its nibble's row that no earlier bit of the nibble writes
+                    u32 st[8], w0[8], w1[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const u32 slotn = hma[k] & 15u;
+                        const u32 *r = R[k >> 2];
+                        const u32 dsel = (slotn & 8u) ? ((slotn & 4u) ? r[3] : r[2]) : ((slotn & 4u) ? r[1] : r[0]);
+                        st[k] = (dsel >> ((slotn & 3u) * 8u)) & 255u;
+                        if (TYPE == ZT_ICM) { w0[k] = cm[st[k]]; w1[k] = 0; }
+                        else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st[k] * 2); w0[k] = w.x; w1[k] = w.y; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        u32 a0 = w0[k], a1 = w1[k];
+#pragma unroll
+                        for (int j = 0; j < k; j++) { const bool same = st[j] == st[k]; a0 = same ? w0[j] : a0; a1 = same ? w1[j] : a1; }
+                        const i32 t32767 = ya[k] ? 32767 : 0;
+                        if (TYPE == ZT_ICM) {
+                            out.set(k, stretch((i32)(a0 >> 8)));
+                            w0[k] = (u32)wadd((i32)a0, (t32767 - (i32)(a0 >> 8)) >> 2);
+                            cm[st[k]] = w0[k];
+                        } else {
+                            const i32 pj = in0.get(k);
+                            const i32 p = clamp2k(wadd(wmul((i32)a0, pj), wmul((i32)a1, 64)) >> 16);
+                            out.set(k, p);
+                            const i32 err = t32767 - squash(p);
+                            w0[k] = (u32)clamp512k(wadd((i32)a0, wadd(wmul(err, pj), 1 << 12) >> 13));
+                            w1[k] = (u32)clamp512k(wadd((i32)a1, (err + 16) >> 5));
+                            *reinterpret_cast<uint2 *>(cm + st[k] * 2) = make_uint2(w0[k], w1[k]);
+                        }
+                        const u32 slotn = hma[k] & 15u, sh = (slotn & 3u) * 8u;
+                        const u32 nsv = s_ns[st[k] * 4 + (u32)ya[k]];   // statetable.v:75-84
+                        u32 *r = R[k >> 2];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) r[q] = (slotn >> 2) == (u32)q ? ((r[q] & ~(255u << sh)) | (nsv << sh)) : r[q];
+                        if ((k & 3) == 3) *reinterpret_cast<u32x4 *>(ht + ro[k >> 2]) = u32x4{r[0], r[1], r[2], r[3]};
+                    }
+                } else if (TYPE == ZT_MATCH) {                   // predictor.v:564-574,710-741 (see the bit-serial code below)
+                    const i32 mask = (i32)(ht_len - 1);
+                    const i32 cmi = (i32)hctx & (i32)(cm_len - 1);
+                    const u32 cand = cm[cmi];                    // read at the end of the byte by the reference; nothing writes it in between
+                    if (ma != 0) mpred = ht[wsub(mlimit, mb) & mask];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        i32 p = 0;
+                        if (ma != 0) {
+                            mc = (i32)((mpred >> (7 - k)) & 1u);
+                            p = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
+                        }
+                        out.set(k, p);
+                        if (mc != ya[k]) ma = 0;
+                    }
+                    ht[mlimit & mask] = (u8)ch;
+                    mlimit = wadd(mlimit, 1) & mask;
+                    if (ma == 0) {
+                        mb = wsub(mlimit, (i32)cand);
+                        if ((mb & mask) != 0) {
+                            while (ma < 255) {                   // four candidate bytes per round trip
+                                u32 x[4], z[4];
+#pragma unroll
+                                for (int t = 0; t < 4; t++) {
+                                    x[t] = ht[wsub(wsub(mlimit, ma), 1 + t) & mask];
+                                    z[t] = ht[wsub(wsub(wsub(mlimit, ma), mb), 1 + t) & mask];
+                                }
+                                int eq = 0;
+#pragma unroll
+                                for (int t = 3; t >= 0; t--) eq = x[t] == z[t] ? eq + 1 : 0;
+                                // eq = equal pairs counted from t = 0 up to the first mismatch
+                                ma = min(ma + eq, 255);
+                                if (eq < 4) break;
+                            }
+                        }
+                    } else if (ma < 255) ma++;
+                    cm[cmi] = (u32)mlimit;
+                } else if (TYPE == ZT_MIX2) {                    // predictor.v:586-599,744-762
+                    u32 idx[8], v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { idx[k] = (hctx + (c8a[k] & (u32)cmask)) & (u32)(cc - 1); v[k] = a16[idx[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        u32 wv_ = v[k];
+#pragma unroll
+                        for (int j = 0; j < k; j++) wv_ = idx[j] == idx[k] ? v[j] : wv_;
+                        const i32 w = (i32)wv_;
+                        const i32 pj = in0.get(k), pk = in1.get(k);
+                        const i32 p = clamp2k(wadd(wmul(w, pj), wmul(65536 - w, pk)) >> 16);
+                        out.set(k, p);
+                        const i32 err = wmul((ya[k] ? 32767 : 0) - squash(p), crate) >> 5;
+                        i32 wn = wadd(w, wadd(wmul(err, wsub(pj, pk)), 1 << 12) >> 13);
+                        wn = min(max(wn, 0), 65535);
+                        v[k] = (u32)wn;
+                        a16[idx[k]] = (u16)wn;
+                    }
+                } else if (TYPE == ZT_MIX) {                     // predictor.v:600-614,763-775; a nibble's four weight rows at a time
+                    const u8 *inb[8];
+#pragma unroll
+                    for (int l = 0; l < 8; l++) inb[l] = reinterpret_cast<const u8 *>(ring_at(l < climit ? cb + l : cb, bi));
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) {
+                        u32 cx[4];
+                        i32 wv[4][8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            cx[q] = (u32)(wadd((i32)hctx, (i32)c8a[4 * nb + q] & cmask) & (cc - 1));
+                            const u32 *wrow = cm + (size_t)wmul((i32)cx[q], climit);
+#pragma unroll
+                            for (int l = 0; l < 8; l++) wv[q][l] = 0;
+                            auto ld = [&](const int at, const int cnt) {
+                                if (cnt >= 4) { const u32x4a t = *reinterpret_cast<const u32x4a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; wv[q][at + 2] = (i32)t.z; wv[q][at + 3] = (i32)t.w; }
+                                else if (cnt == 3) { const u32x3a t = *reinterpret_cast<const u32x3a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; wv[q][at + 2] = (i32)t.z; }
+                                else if (cnt == 2) { const u32x2a t = *reinterpret_cast<const u32x2a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; }
+                                else if (cnt == 1) wv[q][at] = (i32)wrow[at];
+                            };
+                            ld(0, climit);
+                            if (climit > 4) ld(4, climit - 4);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int k = 4 * nb + q;
+#pragma unroll
+                            for (int j = 0; j < q; j++) {
+                                const bool same = cx[j] == cx[q];
+#pragma unroll
+                                for (int l = 0; l < 8; l++) wv[q][l] = same ? wv[j][l] : wv[q][l];
+                            }
+                            i32 pin[8];
+                            i32 sum = 0;
+#pragma unroll
+                            for (int l = 0; l < 8; l++) {
+                                pin[l] = l < climit ? (i32)*reinterpret_cast<const int16_t *>(inb[l] + 2 * k) : 0;
+                                sum = wadd(sum, wmul(wv[q][l] >> 8, pin[l]));
+                            }
+                            const i32 p = clamp2k(sum >> 8);
+                            out.set(k, p);
+                            const i32 err = wmul((ya[k] ? 32767 : 0) - squash(p), crate) >> 4;
+#pragma unroll
+                            for (int l = 0; l < 8; l++) wv[q][l] = clamp512k(wadd(wv[q][l], wadd(wmul(err, pin[l]), 1 << 12) >> 13));
+                            u32 *wrow = cm + (size_t)wmul((i32)cx[q], climit);
+                            auto stw = [&](const int at, const int cnt) {
+                                if (cnt >= 4) *reinterpret_cast<u32x4a *>(wrow + at) = u32x4a{(u32)wv[q][at], (u32)wv[q][at + 1], (u32)wv[q][at + 2], (u32)wv[q][at + 3]};
+                                else if (cnt == 3) *reinterpret_cast<u32x3a *>(wrow + at) = u32x3a{(u32)wv[q][at], (u32)wv[q][at + 1], (u32)wv[q][at + 2]};
+                                else if (cnt == 2) *reinterpret_cast<u32x2a *>(wrow + at) = u32x2a{(u32)wv[q][at], (u32)wv[q][at + 1]};
+                                else if (cnt == 1) wrow[at] = (u32)wv[q][at];
+                            };
+                            stw(0, climit);
+                            if (climit > 4) stw(4, climit - 4);
+                        }
+                    }
+                } else if (TYPE == ZT_SSE) {                     // predictor.v:632-660,792-805
+                    i32 idx[8], wt[8];
+                    u32 iu[8], e0[8], e1[8], nv[8];
+                    bool ok[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const u32 cxt = (hctx + c8a[k]) * 32u;
+                        i32 pq = wadd(in0.get(k), 992);
+                        pq = min(max(pq, 0), 1983);
+                        wt[k] = pq & 63;
+                        pq >>= 6;
+                        idx[k] = wadd((i32)cxt, pq);
+                        ok[k] = idx[k] >= 0 && wadd(idx[k], 1) < (i32)cm_len;
+                        iu[k] = ((u32)idx[k] + (u32)(wt[k] >> 5)) & (cm_len - 1u);
+                        e0[k] = e1[k] = 0;
+                        if (ok[k]) { const u32x2a e = *reinterpret_cast<const u32x2a *>(cm + idx[k]); e0[k] = e.x; e1[k] = e.y; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        u32 a0 = e0[k], a1 = e1[k];
+#pragma unroll
+                        for (int j = 0; j < k; j++) {            // entries an earlier bit of the byte rewrote
+                            a0 = iu[j] == (u32)idx[k] ? nv[j] : a0;
+                            a1 = iu[j] == (u32)idx[k] + 1u ? nv[j] : a1;
+                        }
+                        out.set(k, ok[k] ? stretch(wadd(wmul((i32)(a0 >> 10), 64 - wt[k]), wmul((i32)(a1 >> 10), wt[k])) >> 13) : 0);
+                        u32 v;
+                        if (ok[k] && iu[k] == (u32)idx[k]) v = a0;
+                        else if (ok[k] && iu[k] == (u32)idx[k] + 1u) v = a1;
+                        else v = cm[iu[k]];                      // (outside the pair: issued after the earlier bits' stores)
+                        const i32 err = (ya[k] ? 32767 : 0) - (i32)(v >> 17);
+                        const i32 count = (i32)v & 1023;
+                        if (count < climit) v = (u32)wadd(wadd((i32)v, wadd(wmul(err, climit - count), 1 << 12) >> 13), 1);
+                        nv[k] = v;
+                        cm[iu[k]] = v;
+                    }
+                }
+            } else {
             u32 c8 = 1, hmap4 = 1;
 #pragma unroll 1
             for (int kb = 0; kb < 8; kb++) {
@@ -227,19 +500,22 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                     r3 = (slotn >= 12u) ? ins : r3;
                     if ((kb & 3) == 3) *reinterpret_cast<u32x4 *>(ht + roff) = u32x4{r0, r1, r2, r3};   // the nibble's row goes back
                 } else if (TYPE == ZT_MATCH) {                   // predictor.v:564-574,710-741
+                    // The reference shifts the bit into ht[limit] and, while a match is alive, re-reads the predicted byte
+                    // ht[limit - b] every bit.  Neither byte changes under the other's feet (limit - b == limit needs
+                    // b & mask == 0, and then no match is ever alive), so: the predicted byte is read once per byte, the coded
+                    // byte is written once, whole (eight shifts of a u8 leave exactly the byte).
                     const i32 mask = (i32)(ht_len - 1);
-                    const i32 idx = mlimit & mask;
-                    const u32 cur = ht[idx];
+                    if (kb == 0 && ma != 0) mpred = ht[wsub(mlimit, mb) & mask];
                     if (ma == 0) p = 0;
                     else {
-                        mc = (i32)(((u32)ht[wsub(mlimit, mb) & mask] >> (7u - mcxt)) & 1u);
+                        mc = (i32)((mpred >> (7u - mcxt)) & 1u);
                         p = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
                     }
                     if (mc != y) ma = 0;
-                    ht[idx] = (u8)((cur << 1) | (u32)y);
                     mcxt++;
                     if (mcxt >= 8) {
                         mcxt = 0;
+                        ht[mlimit & mask] = (u8)ch;
                         mlimit = wadd(mlimit, 1) & mask;
                         const i32 cmi = (i32)hctx & (i32)(cm_len - 1);
                         if (ma == 0) {
@@ -269,17 +545,33 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                 } else if (TYPE == ZT_MIX) {                     // predictor.v:600-614,763-775
                     const u32 cxt = (u32)(wadd((i32)hctx, (i32)c8 & cmask) & (cc - 1));
                     u32 *const wrow = cm + (size_t)wmul((i32)cxt, climit);
+                    // the row of m <= 8 weights: one or two vector accesses (word-aligned) instead of m
                     i32 wv[8], pin[8];
 #pragma unroll
-                    for (int l = 0; l < 8; l++) wv[l] = l < climit ? (i32)wrow[l] : 0;
+                    for (int l = 0; l < 8; l++) wv[l] = 0;
+                    auto ld = [&](const int at, const int cnt) {
+                        if (cnt >= 4) { const u32x4a v = *reinterpret_cast<const u32x4a *>(wrow + at); wv[at] = (i32)v.x; wv[at + 1] = (i32)v.y; wv[at + 2] = (i32)v.z; wv[at + 3] = (i32)v.w; }
+                        else if (cnt == 3) { const u32x3a v = *reinterpret_cast<const u32x3a *>(wrow + at); wv[at] = (i32)v.x; wv[at + 1] = (i32)v.y; wv[at + 2] = (i32)v.z; }
+                        else if (cnt == 2) { const u32x2a v = *reinterpret_cast<const u32x2a *>(wrow + at); wv[at] = (i32)v.x; wv[at + 1] = (i32)v.y; }
+                        else if (cnt == 1) wv[at] = (i32)wrow[at];
+                    };
+                    ld(0, climit);
+                    if (climit > 4) ld(4, climit - 4);
                     i32 sum = 0;
 #pragma unroll
                     for (int l = 0; l < 8; l++) { pin[l] = inm[l].get(kb); sum = wadd(sum, wmul(wv[l] >> 8, pin[l])); }
                     p = clamp2k(sum >> 8);
                     const i32 err = wmul(t32767 - squash(p), crate) >> 4;
 #pragma unroll
-                    for (int l = 0; l < 8; l++)
-                        if (l < climit) wrow[l] = (u32)clamp512k(wadd(wv[l], wadd(wmul(err, pin[l]), 1 << 12) >> 13));
+                    for (int l = 0; l < 8; l++) wv[l] = clamp512k(wadd(wv[l], wadd(wmul(err, pin[l]), 1 << 12) >> 13));
+                    auto st = [&](const int at, const int cnt) {
+                        if (cnt >= 4) *reinterpret_cast<u32x4a *>(wrow + at) = u32x4a{(u32)wv[at], (u32)wv[at + 1], (u32)wv[at + 2], (u32)wv[at + 3]};
+                        else if (cnt == 3) *reinterpret_cast<u32x3a *>(wrow + at) = u32x3a{(u32)wv[at], (u32)wv[at + 1], (u32)wv[at + 2]};
+                        else if (cnt == 2) *reinterpret_cast<u32x2a *>(wrow + at) = u32x2a{(u32)wv[at], (u32)wv[at + 1]};
+                        else if (cnt == 1) wrow[at] = (u32)wv[at];
+                    };
+                    st(0, climit);
+                    if (climit > 4) st(4, climit - 4);
                 } else if (TYPE == ZT_SSE) {                     // predictor.v:632-660,792-805
                     const u32 cxt = (hctx + c8) * 32u;
                     i32 pq = wadd(in0.get(kb), 992);
@@ -289,7 +581,7 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                     const i32 idx = wadd((i32)cxt, pq), idx2 = wadd(idx, 1);
                     const bool ok = idx >= 0 && idx2 < (i32)cm_len;
                     u32 e0 = 0, e1 = 0;
-                    if (ok) { e0 = cm[idx]; e1 = cm[idx2]; }
+                    if (ok) { const u32x2a e = *reinterpret_cast<const u32x2a *>(cm + idx); e0 = e.x; e1 = e.y; }
                     p = ok ? stretch(wadd(wmul((i32)(e0 >> 10), 64 - wt), wmul((i32)(e1 >> 10), wt)) >> 13) : 0;
                     const i32 iu = (i32)((u32)idx + (u32)(wt >> 5)) & (i32)(cm_len - 1);
                     u32 v;
@@ -308,6 +600,7 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                 else if (c8 >= 16u && c8 < 32u) hmap4 = ((hmap4 & 0xfu) << 5) | ((u32)y << 4) | 1u;
                 else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
             }
+            }
             *ring_at(ci, bi) = make_uint4(out.a, out.b, out.c, out.d);
             {   // ZPAQL.run(byte) of the shipped hash chain: H[ci] for the next byte
                 u32 a = ch;
@@ -316,6 +609,10 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                 prev = ch;
             }
         }
+#ifdef ZPG_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const_cast<Stage &>(S).busy += __builtin_readcyclecounter() - t_in;
+#endif
         lds_barrier();
     }
 }
@@ -323,13 +620,11 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
 // the coder wave (encoder.v:48-139): byte it - n, predictions from the last component's ring; returns the bytes written
 __device__ __forceinline__ u32 coder_stage(const Stage &S)
 {
-    const DBatch &B = *S.B;
     u8 *const lds = S.lds;
     const u16 *s_squash = reinterpret_cast<const u16 *>(lds + L_SQUASH);
     const int n = S.n;
     const GCfg &G = *S.cfg;
     const uint4 *const link = reinterpret_cast<const uint4 *>(lds + L_LINK);
-    const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
     u32 low = 1, high = 0xFFFFFFFFu, opos = 0;
     u8 *const dst = S.dst;
     const u32 cap = S.cap;
@@ -340,17 +635,11 @@ __device__ __forceinline__ u32 coder_stage(const Stage &S)
             low <<= 8; high = (high << 8) | 255u; low = low ? low : 1u;
         }
     };
-    auto byte_at = [&](const u32 bi) -> u32 {
-        const u32 pos = pp ? (bi ? bi - 1u : 0u) : bi;
-        const u32 v = (bi < S.total) ? (u32)S.src[pos] : 0u;
-        return (pp && bi == 0) ? 0u : v;
-    };
-    u32 ch_next = S.active ? byte_at(0) : 0u;
+    const u8 *const s_bytes = lds + L_BYTES;
     for (u32 it = 0; it < S.iters; it++) {
         const u32 bi = it - (u32)n;
         if (S.active && bi < S.total) {
-            const u32 ch = ch_next;
-            ch_next = byte_at(bi + 1u);
+            const u32 ch = s_bytes[(bi & 15u) * BPW + S.lane];
             const uint4 x = link[((u32)G.roff[n - 1] + (bi & (u32)G.rmask[n - 1])) * BPW + S.lane];
             const P8 pr = {x.x, x.y, x.z, x.w};
             low += 1;                                            // EOF flag: encode(0, 0) (encoder.v:108)
@@ -376,6 +665,7 @@ __device__ __forceinline__ u32 coder_stage(const Stage &S)
     return opos;
 }
 
+template <bool BATCH>
 __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
 {
     extern __shared__ __align__(16) u8 lds[];
@@ -447,17 +737,21 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
         __syncthreads();
         S.iters = *misc + (u32)n;
         S.hashes = cfg.hashes;
+        S.busy = 0;
+#ifdef ZPG_PROF
+        const u64 t_all = __builtin_readcyclecounter();
+#endif
         if (wave < n) {
             switch (M.comp[wave].type) {                         // uniform per wave
-            case ZT_CONST: comp_stage<ZT_CONST>(S); break;
-            case ZT_CM: comp_stage<ZT_CM>(S); break;
-            case ZT_ICM: comp_stage<ZT_ICM>(S); break;
-            case ZT_MATCH: comp_stage<ZT_MATCH>(S); break;
-            case ZT_AVG: comp_stage<ZT_AVG>(S); break;
-            case ZT_MIX2: comp_stage<ZT_MIX2>(S); break;
-            case ZT_MIX: comp_stage<ZT_MIX>(S); break;
-            case ZT_ISSE: comp_stage<ZT_ISSE>(S); break;
-            default: comp_stage<ZT_SSE>(S); break;
+            case ZT_CONST: comp_stage<ZT_CONST, BATCH>(S); break;
+            case ZT_CM: comp_stage<ZT_CM, BATCH>(S); break;
+            case ZT_ICM: comp_stage<ZT_ICM, BATCH>(S); break;
+            case ZT_MATCH: comp_stage<ZT_MATCH, BATCH>(S); break;
+            case ZT_AVG: comp_stage<ZT_AVG, BATCH>(S); break;
+            case ZT_MIX2: comp_stage<ZT_MIX2, BATCH>(S); break;
+            case ZT_MIX: comp_stage<ZT_MIX, BATCH>(S); break;
+            case ZT_ISSE: comp_stage<ZT_ISSE, BATCH>(S); break;
+            default: comp_stage<ZT_SSE, BATCH>(S); break;
             }
         } else {
             const u32 opos = coder_stage(S);
@@ -466,6 +760,11 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
                 B.status[blk] = opos > S.cap ? ZPQ_E_OVERFLOW : ZPQ_OK;
             }
         }
+#ifdef ZPG_PROF
+        if (blockIdx.x == 0 && lane == 0 && wave < n)
+            printf("wave %d type %d: busy %llu of %llu cycles, %u bytes\n", wave, M.comp[wave].type, (unsigned long long)S.busy,
+                   (unsigned long long)(__builtin_readcyclecounter() - t_all), S.iters);
+#endif
         __syncthreads();
     }
 }
@@ -489,7 +788,7 @@ static bool gpipe_cfg(const DModel *M, zpqg::GCfg *cfg, size_t *lds_bytes)
         auto need = [&](int j) { if (j < 0 || j >= i) return false; if (i - j > far[j]) far[j] = i - j; return true; };
         switch (c.type) {
         case ZT_CONST: case ZT_CM: case ZT_ICM: break;
-        case ZT_MATCH: if (c.cm_len < 1 || c.ht_len < 1) return false; break;
+        case ZT_MATCH: if (c.cm_len < 1 || c.ht_len < 2) return false; break;   // (one-byte buffer: the predicted byte IS the coded byte)
         case ZT_AVG: if (!need(c.a) || !need(c.b)) return false; break;
         case ZT_MIX2: if (!need(c.j) || !need(c.k)) return false; break;
         case ZT_MIX:
@@ -508,7 +807,7 @@ static bool gpipe_cfg(const DModel *M, zpqg::GCfg *cfg, size_t *lds_bytes)
         cfg->roff[i] = (uint16_t)total; cfg->rmask[i] = (uint16_t)(depth - 1);
         total += depth;
     }
-    cfg->n = n; cfg->ring = total; cfg->hashes = hashes; cfg->types = 0;
+    cfg->n = n; cfg->ring = total; cfg->hashes = hashes;
     *lds_bytes = (size_t)zpqg::L_LINK + (size_t)total * zpqg::BPW * 16 + 16;
     return *lds_bytes <= 160 * 1024;
 }
@@ -540,7 +839,13 @@ extern "C" int zpq_launch_gpipe(const DBatch *B, const DModel *hostM, int nslots
     size_t lds = 0;
     if (!gpipe_cfg(hostM, &cfg, &lds)) return ZPQ_E_INTERNAL;
     const int nwg = (nslots + zpqg::BPW - 1) / zpqg::BPW;
-    (void)hipFuncSetAttribute((const void *)zpqg::k_gpipe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(zpqg::k_gpipe, dim3(nwg), dim3(64 * (cfg.n + 1)), lds, stream, *B, cfg);
+    const char *ev = getenv("ZPQ_GPIPE_BATCH");                   // "0": the bit-serial stages (tests compare the two)
+    if (ev && atoi(ev) == 0) {
+        (void)hipFuncSetAttribute((const void *)zpqg::k_gpipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(zpqg::k_gpipe<false>, dim3(nwg), dim3(64 * (cfg.n + 1)), lds, stream, *B, cfg);
+    } else {
+        (void)hipFuncSetAttribute((const void *)zpqg::k_gpipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(zpqg::k_gpipe<true>, dim3(nwg), dim3(64 * (cfg.n + 1)), lds, stream, *B, cfg);
+    }
     return ZPQ_OK;
 }
