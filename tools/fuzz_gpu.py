@@ -23,6 +23,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--only", type=int, default=-1, help="run only batch number N of the seed's sequence")
+ap.add_argument("--general", action="store_true", help="general models: random mixes of the nine component types (inputs = earlier "
+                "components, hash-chain program), C4b, levels 2-3 as general models -- the wave-per-component encoder k_gpipe in its "
+                "byte-batched and bit-serial forms, decoded back by k_rows")
 a = ap.parse_args()
 
 z = ge.load()
@@ -32,6 +35,44 @@ rnd = random.Random(a.seed)
 t_end = time.time() + a.seconds
 names = {}
 nbatch = nblocks = nbytes = 0
+
+
+HC = [74, 18, 104, 95, 0] + [59, 112, 25] * 7 + [59, 112, 56, 0]
+
+
+def random_model(r):
+    """A header with 1..12 components of random type whose inputs are earlier components."""
+    n = r.randint(1, 12)
+    comps = []
+    for i in range(n):
+        kinds = [1, 2, 3, 4] + ([5, 6, 7, 8, 9] * 2 if i else [])
+        t = r.choice(kinds)
+        j = r.randrange(i) if i else 0
+        k = r.randrange(i) if i else 0
+        if t == 1:
+            c = [1, r.randrange(256)]
+        elif t == 2:
+            c = [2, r.randint(6, 16), r.randint(1, 255)]
+        elif t == 3:
+            c = [3, r.randint(5, 14)]
+        elif t == 4:
+            c = [4, r.randint(6, 14), r.randint(1, 14)]
+        elif t == 5:
+            c = [5, j, k, r.randrange(256)]
+        elif t == 6:
+            c = [6, r.randint(0, 10), j, k, r.randint(1, 30), r.choice([0, 255, 15, 3])]
+        elif t == 7:
+            m = r.randint(1, min(8, i))
+            c = [7, r.randint(0, 8), r.randint(0, i - m), m, r.randint(1, 30), r.choice([0, 255, 15])]
+        elif t == 8:
+            c = [8, r.randint(5, 14), j]
+        else:
+            c = [9, r.randint(1, 8), j, r.randint(1, 32), r.randint(1, 255)]
+        comps.append(c)
+    b = [4, 16, 0, 0, n]
+    for c in comps:
+        b += c
+    return bytes(b + [0] + HC), comps
 
 
 def make(kind, n, r):
@@ -60,16 +101,29 @@ while time.time() < t_end:
             break
         continue
     which = r.choice([1, 1, 2, 2, 2, 3, 3, 4, 5, "c4b"])
-    header = C4B if which == "c4b" else O.level_header(which)
+    lanes_flag = 0
+    if a.general:
+        which = r.choice(["rnd", "rnd", "rnd", "c4b", "c4b", 2, 3])
+        lanes_flag = z.FLAG_LANES if which in (2, 3) else 0
+    if which == "rnd":
+        header, comps = random_model(r)
+        which = "rnd%s" % comps
+    else:
+        header = C4B if which == "c4b" else O.level_header(which)
     model = z.Model(header=header)
     nb = r.choice([1, 2, 5, 11, 12, 13, 16, 17, 31, 33, 64, 100, 150])
-    if which in (4, 5, "c4b"):
+    if which in (4, 5, "c4b") and not a.general:
         nb = min(nb, 33)
     maxlen = r.choice([0, 1, 7, 64, 300, 2000, 9000])
     blocks = [make(r.randrange(6), r.randint(0, maxlen) if r.random() < 0.8 else maxlen, r) for _ in range(nb)]
     pp = r.random() < 0.7
-    flags = z.FLAG_PP if pp else 0
+    flags = (z.FLAG_PP if pp else 0) | lanes_flag
     env = {}
+    if a.general:
+        nb = r.choice([1, 2, 5, 33, 64, 65, 100, 150, 200])
+        blocks = [make(r.randrange(6), r.randint(0, maxlen) if r.random() < 0.8 else maxlen, r) for _ in range(nb)]
+        if r.random() < 0.3:
+            env["ZPQ_GPIPE_BATCH"] = "0"
     if which in (1, 2, 3) and r.random() < 0.3:
         env["ZPQ_SPARSE_FORCE_LOG2"] = str(r.choice([12, 13, 15]))
     elif which in (1, 2, 3) and r.random() < 0.3:

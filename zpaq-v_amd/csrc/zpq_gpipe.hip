@@ -827,8 +827,8 @@ extern "C" int zpq_gpipe_blocks_per_cu(const DModel *M)
     zpqg::GCfg cfg;
     size_t lds = 0;
     if (!gpipe_cfg(M, &cfg, &lds)) return 0;
-    const int wgs = (int)((160 * 1024) / lds);                 // workgroups per CU by LDS; waves: n + 1 of 32 per CU
-    const int by_waves = 32 / (cfg.n + 1);
+    const int wgs = (int)((160 * 1024) / lds);                 // workgroups per CU by LDS; waves: n + 1 of the 16 that 128 VGPRs allow
+    const int by_waves = 16 / (cfg.n + 1);
     const int w = wgs < by_waves ? wgs : by_waves;
     return (w < 1 ? 1 : w) * zpqg::BPW;
 }
