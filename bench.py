@@ -41,6 +41,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # A(L) = 1 + r + 64*K_h + 2 + 32*[MIX2]; the table holds A(L) - r
 ALG_BYTES_PER_INPUT_BYTE_L = {1: 131, 2: 195, 3: 323, 4: 419, 5: 547}
 ALG_BYTES_C4B = 211
+RANDOM_LINE_CEILING_G = 48.2       # G random 64-byte lines per second, MI355X, measured (tools/micro/linerate.hip)
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 LEVEL_NAMES = {1: "ICM16+ISSE19", 2: "ICM16+ISSE16+ISSE16", 3: "ICM18+4xISSE18", 4: "ICM20+5xISSE20+MIX2",
                5: "ICM22+7xISSE22+MIX2"}
@@ -367,6 +368,20 @@ def main():
         traffic, tnote = measured_traffic(roof["kernel"], nb)
         roof["traffic"] = traffic
         roof["traffic_source"] = tnote
+        if traffic:
+            # What the memory system gives THIS access pattern: the traffic is random 64-byte lines (16 bytes used of each) plus
+            # the streaming clear of the tables.  tools/micro/linerate.hip on MI355X (profiles/r03_linerate.txt): 48.2-48.7 G
+            # random lines/s read-only (3.1 TB/s), 25.3 G lines/s read + written back (50.6 G transfers/s), flat over
+            # occupancy and loads in flight; the clear runs at 6.9 TB/s (tools/init_time.py: 14.7-15.3 ms per launch).
+            clear_bytes = float(ctx.last_slots) * model.state_bytes if not ctx.last_line_store else 0.0
+            clear_ms = clear_bytes / 6.9e12 * 1e3
+            dom_ms = max(enc_ms, dec_ms)
+            glines = (traffic - clear_bytes) / 64.0 / ((dom_ms - clear_ms) * 1e-3) / 1e9
+            roof["random_lines"] = {"ceiling_G_per_s": RANDOM_LINE_CEILING_G, "achieved_G_per_s": round(glines, 2),
+                                    "frac": round(glines / RANDOM_LINE_CEILING_G, 4), "clear_bytes": int(clear_bytes),
+                                    "clear_ms_at_6.9TBps": round(clear_ms, 2),
+                                    "what": "(traffic - table clear) / 64 B over (kernel time - clear time), against the chip's measured "
+                                            "rate for random 64-byte lines (profiles/r03_linerate.txt)"}
         roof["cycles_per_coded_bit_at_2.4GHz"] = round(max(enc_ms, dec_ms) * 1e-3 * 2.4e9 / ((size + 1) * 8), 1)
         res = {
             "metric": "MB/s (comp+decomp) on level-2 64KiB blocks", "value": round(value, 2), "unit": "MB/s",
