@@ -169,3 +169,14 @@ def test_which_general_models_the_wave_pipeline_encodes(zpq, monkeypatch):
     assert L.zpq_gpipe_applies(zpq.Model(header=other).h) == 0
     monkeypatch.setenv("ZPQ_ENC_GPIPE", "0")
     assert L.zpq_gpipe_applies(zpq.Model(header=C4B).h) == 0
+    # the decoder of the same waves (k_gdec) takes the same models
+    L.zpq_gdec_applies.argtypes = [C.c_void_p]
+    L.zpq_gdec_applies.restype = C.c_int
+    monkeypatch.delenv("ZPQ_DEC_GPIPE", raising=False)
+    for name in TAKEN:
+        assert L.zpq_gdec_applies(zpq.Model(header=hdr(MODELS[name])).h) == 1, name
+    for name in LEFT:
+        assert L.zpq_gdec_applies(zpq.Model(header=hdr(MODELS[name])).h) == 0, name
+    assert L.zpq_gdec_applies(zpq.Model(header=C4B).h) == 1
+    monkeypatch.setenv("ZPQ_DEC_GPIPE", "0")
+    assert L.zpq_gdec_applies(zpq.Model(header=C4B).h) == 0

@@ -1,6 +1,7 @@
 """GPU parity: the wave-per-component ENCODER of general models (k_gpipe, zpq_gpipe.hip: wave = component, lane = block,
 predictions handed from wave to wave through LDS rings) against the CPU oracle and against the lane-per-component encoder
-(k_rows / k_lanes) on the same batches.  Decoding stays with k_rows / k_lanes: every batch is decoded back."""
+(k_rows / k_lanes) on the same batches; and their bit-synchronous DECODER (k_gdec: the same waves, a barrier per level of the
+prediction chain) against k_rows / k_lanes on the same streams."""
 import os
 import random
 import sys
@@ -41,6 +42,26 @@ def both_encoders(zpq, ctx, model, blocks, flags, cap=None):
     return name, pipe, st1, len1, other, rows, st2, len2
 
 
+def both_decoders(zpq, ctx, model, coded, blocks, flags, cap, intact=True):
+    """The wave-per-component decoder (k_gdec) and the lane-per-component one on the same streams: blocks, status, bytes
+    consumed, PP byte and the coder's last window must agree, and equal what was encoded."""
+    got = ctx.decode_blocks(model, coded, cap=cap, flags=flags)
+    assert ctx.last_kernel_name == "k_gdec<decode>"
+    os.environ["ZPQ_DEC_GPIPE"] = "0"
+    try:
+        ref = ctx.decode_blocks(model, coded, cap=cap, flags=flags)
+        assert ctx.last_kernel_name in ("k_rows<decode>", "k_lanes<decode>")
+    finally:
+        del os.environ["ZPQ_DEC_GPIPE"]
+    dec, status, consumed, code, first = got
+    assert dec == ref[0] and all(list(a) == list(b) for a, b in zip(got[1:], ref[1:]))
+    ok = [i for i in range(len(blocks)) if status[i] == 0 and intact]
+    assert all(dec[i] == blocks[i] and int(consumed[i]) == len(coded[i]) for i in ok)
+    if flags & zpq.FLAG_PP:
+        assert all(int(first[i]) == 0 for i in ok)
+    return status
+
+
 @pytest.mark.parametrize("name", TAKEN)
 def test_every_component_type_alone(zpq, gpu_ctx, name):
     header = hdr(MODELS[name])
@@ -54,8 +75,7 @@ def test_every_component_type_alone(zpq, gpu_ctx, name):
         want = [O.Codec(header).encode(b, pp=pp) for b in blocks]
         assert rows == want
         assert pipe == want
-        dec, status, consumed, _, first = gpu_ctx.decode_blocks(model, pipe, cap=4200, flags=flags)
-        assert (status == 0).all() and dec == blocks
+        assert (both_decoders(zpq, gpu_ctx, model, pipe, blocks, flags, 4200) == 0).all()
 
 
 @pytest.mark.parametrize("level", [2, 3, 4, 5])
@@ -67,6 +87,7 @@ def test_shipped_levels(zpq, gpu_ctx, level):
     name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, F)
     assert name_ == "k_gpipe<encode>" and (st1 == 0).all()
     assert pipe == [O.Codec(O.level_header(level)).encode(b) for b in blocks] == rows
+    assert (both_decoders(zpq, gpu_ctx, model, pipe, blocks, F, 5016) == 0).all()
 
 
 def test_all_nine_types_ragged_batch_slot_reuse_and_overflow(zpq, gpu_ctx):
@@ -79,17 +100,25 @@ def test_all_nine_types_ragged_batch_slot_reuse_and_overflow(zpq, gpu_ctx):
     name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, zpq.FLAG_PP)
     assert name_ == "k_gpipe<encode>" and other == "k_rows<encode>" and (st1 == 0).all() and (st2 == 0).all()
     assert pipe == want and rows == want
+    assert (both_decoders(zpq, gpu_ctx, model, want, blocks, zpq.FLAG_PP, 7016) == 0).all()
     zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 70 * model.state_bytes + 100)
     try:
         reuse, status, _ = gpu_ctx.encode_blocks(model, blocks)
         assert gpu_ctx.last_kernel_name == "k_gpipe<encode>" and gpu_ctx.last_slots == 70
         assert (status == 0).all() and reuse == want
+        assert (both_decoders(zpq, gpu_ctx, model, want, blocks, zpq.FLAG_PP, 7016) == 0).all() and gpu_ctx.last_slots == 70
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
     small = [INPUTS["lcg4k"], b"abc", INPUTS["text2k"]]
     _, status, out_len = gpu_ctx.encode_blocks(model, small, cap=64)
     assert gpu_ctx.last_kernel_name == "k_gpipe<encode>"
     assert list(status) == [-7, 0, -7] and [int(x) for x in out_len] == [len(O.Codec(C4B).encode(b)) for b in small]
+    # a decoder whose output buffer is too small stops that block with the same status; the others are untouched
+    coded = [O.Codec(C4B).encode(b) for b in small]
+    status = both_decoders(zpq, gpu_ctx, model, coded, small, zpq.FLAG_PP, 100)
+    assert list(status) == [-7, 0, -7]
+    # a stream cut short decodes to SOMETHING on both decoders alike (zeros are read past the end): no hang, no fault
+    both_decoders(zpq, gpu_ctx, model, [c[:len(c) // 2] for c in coded], small, zpq.FLAG_PP, 5000, intact=False)
 
 
 def test_long_input_distances_need_a_deeper_ring(zpq, gpu_ctx):
@@ -101,3 +130,4 @@ def test_long_input_distances_need_a_deeper_ring(zpq, gpu_ctx):
     name_, pipe, st1, _, other, rows, st2, _ = both_encoders(zpq, gpu_ctx, model, blocks, zpq.FLAG_PP)
     assert name_ == "k_gpipe<encode>" and (st1 == 0).all()
     assert pipe == [O.Codec(header).encode(b) for b in blocks] == rows
+    assert (both_decoders(zpq, gpu_ctx, model, pipe, blocks, zpq.FLAG_PP, 2100) == 0).all()

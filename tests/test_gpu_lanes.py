@@ -82,9 +82,17 @@ def run_parity(zpq, ctx, header, blocks, cap=None):
             del os.environ["ZPQ_ENC_GPIPE"]
         assert ctx.last_kernel_name in ("k_lanes<encode>", "k_rows<encode>") and (status == 0).all() and other == want
     dec, status, consumed, _, first = ctx.decode_blocks(model, coded, cap=max(len(b) for b in blocks) + 16, flags=F)
-    assert ctx.last_kernel_name in ("k_lanes<decode>", "k_rows<decode>")
+    assert ctx.last_kernel_name in ("k_lanes<decode>", "k_rows<decode>", "k_gdec<decode>")
     assert (status == 0).all() and dec == blocks and (first == 0).all()
     assert [int(c) for c in consumed] == [len(c) for c in coded]
+    if ctx.last_kernel_name == "k_gdec<decode>":         # the lane-per-component decoder stays covered
+        os.environ["ZPQ_DEC_GPIPE"] = "0"
+        try:
+            dec, status, consumed, _, first = ctx.decode_blocks(model, coded, cap=max(len(b) for b in blocks) + 16, flags=F)
+        finally:
+            del os.environ["ZPQ_DEC_GPIPE"]
+        assert ctx.last_kernel_name in ("k_lanes<decode>", "k_rows<decode>")
+        assert (status == 0).all() and dec == blocks and [int(c) for c in consumed] == [len(c) for c in coded]
     return coded
 
 
@@ -199,6 +207,7 @@ def test_c4b_at_baseline_block_size(zpq, gpu_ctx, nb):
                               in_off.data_ptr(), d_dlen.data_ptr(), d_cons.data_ptr(), d_code.data_ptr(),
                               d_first.data_ptr(), d_dst.data_ptr())
     gpu_ctx.sync()
+    assert gpu_ctx.last_kernel_name == "k_gdec<decode>"
     assert bool((d_st == 0).all()) and bool((d_dst == 0).all()) and bool((d_dlen == size).all())
     assert bool(torch.equal(d_dec, d_in)) and bool(torch.equal(d_cons, d_len)) and bool((d_first == 0).all())
     out, lens = d_out.cpu().numpy(), d_len.cpu().numpy()
@@ -213,7 +222,8 @@ def test_four_blocks_per_wave_equals_one_block_per_wave(zpq, gpu_ctx, monkeypatc
     16-lane row); the one-block-per-wave kernel stays for everything else.  Same model, same blocks, both kernels:
     identical streams, equal to the oracle; a ragged batch so that rows of one wave end at different times, more blocks
     than one workgroup holds, and a budget that makes rows reuse their slots."""
-    monkeypatch.setenv("ZPQ_ENC_GPIPE", "0")             # (the encoder under test here is k_rows, not the wave pipeline)
+    monkeypatch.setenv("ZPQ_ENC_GPIPE", "0")             # (the kernels under test here are k_rows / k_lanes, not the wave pipelines)
+    monkeypatch.setenv("ZPQ_DEC_GPIPE", "0")
     model = zpq.Model(header=C4B)
     rnd = random.Random(16)
     blocks = [bytes(W.make_block(7 * b + 1, rnd.choice([0, 1, 5, 64, 700, 2500, 6000]))) for b in range(41)]

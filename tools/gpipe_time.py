@@ -18,6 +18,7 @@ res = {}
 n = nb or ctx.resident_capacity(model, flags)
 for gp in ("1", "0"):
     os.environ["ZPQ_ENC_GPIPE"] = gp
+    os.environ["ZPQ_DEC_GPIPE"] = gp
     arr = W.make_blocks_fast(n, size)
     d_in = torch.from_numpy(arr.reshape(-1)).to(dev)
     cap = size * (6 if which == "c4b" else 2) + 1024

@@ -36,6 +36,9 @@ extern "C" const char *zpq_lanes_kernel_name(const DModel *M, int decode);   // 
 extern "C" int zpq_gpipe_applies(const DModel *M);
 extern "C" int zpq_gpipe_blocks_per_cu(const DModel *M);
 extern "C" int zpq_launch_gpipe(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream);
+extern "C" int zpq_gdec_applies(const DModel *M);               // ... and their DECODER, bit-synchronous, a barrier per level of the prediction chain
+extern "C" int zpq_gdec_blocks_per_cu(const DModel *M);
+extern "C" int zpq_launch_gdec(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream);
 extern "C" int zpq_chain_blocks_per_wg(const DModel *M);   // 0 = model not supported by the chain kernel
 extern "C" int zpq_chain_max_wgs(const DModel *M, int cus);
 extern "C" int zpq_chain_plan(const DModel *M, int nblocks, int cus, int *blocks_per_wg);
@@ -319,6 +322,7 @@ struct BatchArgs {
 struct Plan {
     bool chain = false, lanes = false;
     bool gpipe = false;          // lanes family, encode: the wave-per-component pipeline (zpq_gpipe.hip)
+    bool gdec = false;           // lanes family, decode: the wave-per-component decoder (zpq_gpipe.hip, k_gdec)
     bool touch = false;          // dense tables that are not cleared: "touched" bitmaps (zpq_touch_layout)
     uint32_t sp = 0;             // compact line store capacity (lines), 0 = dense tables
     const DModel *M = nullptr;   // layout the kernels see (dense or compact)
@@ -404,7 +408,8 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
         if (max_by_mem == 0 && !own_slot) return ZPQ_E_NOMEM;
         nslots = nblocks;
         P->gpipe = P->lanes && !decode && zpq_gpipe_applies(&M) != 0;
-        const int cap_res = c->cus * (P->gpipe ? zpq_gpipe_blocks_per_cu(&M) : P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
+        P->gdec = P->lanes && decode && zpq_gdec_applies(&M) != 0;
+        const int cap_res = c->cus * (P->gpipe ? zpq_gpipe_blocks_per_cu(&M) : P->gdec ? zpq_gdec_blocks_per_cu(&M) : P->lanes ? zpq_lanes_blocks_per_cu(&M) : zpq_generic_blocks_per_cu(&M));
         if (nslots > cap_res) nslots = cap_res;
         if (!own_slot && (uint64_t)nslots > max_by_mem) nslots = (int)max_by_mem;
         grid = nslots;
@@ -479,6 +484,10 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
         rc = zpq_launch_gpipe(&B, &M, nslots, c->stream);
         if (rc != ZPQ_OK) return rc;
         c->last_name = "k_gpipe<encode>";
+    } else if (want_lanes && P.gdec) {
+        rc = zpq_launch_gdec(&B, &M, nslots, c->stream);
+        if (rc != ZPQ_OK) return rc;
+        c->last_name = "k_gdec<decode>";
     } else if (want_lanes) {
         rc = zpq_launch_lanes(&B, &M, decode, nslots, c->stream);
         if (rc != ZPQ_OK) return rc;

@@ -60,6 +60,10 @@ struct GCfg {
     uint16_t roff[16];           // component j's ring starts here ...
     uint16_t rmask[16];          // ... and keeps rmask[j] + 1 bytes: a power of two > the distance to its farthest consumer
     int32_t hashes;              // links of the HCOMP hash chain: H[i], i >= hashes, stays 0
+    int32_t bpw;                 // decoder: blocks (lanes in use) per workgroup: 64, or fewer so that a small batch still fills every workgroup slot
+    int32_t nlevels;             // decoder: levels of the prediction chain (level 0 = no inputs, level k = 1 + the deepest input)
+    uint8_t level[16];           // decoder: component i predicts at this level
+    uint8_t dslot[16];           // decoder: an SSE component's row buffer in LDS
 };
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
@@ -665,6 +669,33 @@ __device__ __forceinline__ u32 coder_stage(const Stage &S)
     return opos;
 }
 
+// Predictor.init + ZPAQL.clear for the nact blocks of a workgroup's round (predictor.v:325-470): zero, then the non-zero fills
+__device__ __forceinline__ void init_slots(const DBatch &B, const DModel &M, const int n, const int wg_slot0, const int nact, const int tid, const int nthr)
+{
+    const u64 n16 = M.zero_bytes / 16;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    for (int b = 0; b < nact; b++) {
+        uint4 *z4 = reinterpret_cast<uint4 *>(B.slots + (u64)(wg_slot0 + b) * M.slot_bytes);
+        for (u64 i = tid; i < n16; i += nthr) z4[i] = zero;
+    }
+    __syncthreads();
+    for (int b = 0; b < nact; b++) {
+        u8 *sl = B.slots + (u64)(wg_slot0 + b) * M.slot_bytes;
+        for (int c = 0; c < n; c++) {
+            const DComp &cc = M.comp[c];
+            if (cc.cm_len && cc.cm_fill != ZF_ZERO) {
+                u32 *t = reinterpret_cast<u32 *>(sl + cc.cm_off);
+                if (cc.cm_fill == ZF_CONST) { for (u32 i = tid; i < cc.cm_len; i += nthr) t[i] = cc.cm_fill_val; }
+                else { const u32 *img = B.img + cc.cm_fill_val; for (u32 i = tid; i < cc.cm_len; i += nthr) t[i] = img[i % cc.cm_pat_len]; }
+            }
+            if (cc.a16_len && cc.a16_fill) {
+                u16 *t = reinterpret_cast<u16 *>(sl + cc.a16_off);
+                for (u32 i = tid; i < cc.a16_len; i += nthr) t[i] = (u16)cc.a16_fill;
+            }
+        }
+    }
+}
+
 template <bool BATCH>
 __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
 {
@@ -697,31 +728,8 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
         const int blk = base + lane;
         const bool active = lane_on && blk < B.nblocks;
         const int nact = min(wg_slots, B.nblocks - base);
-        {   // ---- Predictor.init + ZPAQL.clear for the round's blocks (predictor.v:325-470): zero, then the non-zero fills
-            const u64 n16 = M.zero_bytes / 16;
-            const uint4 zero = make_uint4(0, 0, 0, 0);
-            for (int b = 0; b < nact; b++) {
-                uint4 *z4 = reinterpret_cast<uint4 *>(B.slots + (u64)(wg_slot0 + b) * M.slot_bytes);
-                for (u64 i = tid; i < n16; i += nthr) z4[i] = zero;
-            }
-            __syncthreads();
-            for (int b = 0; b < nact; b++) {
-                u8 *sl = B.slots + (u64)(wg_slot0 + b) * M.slot_bytes;
-                for (int c = 0; c < n; c++) {
-                    const DComp &cc = M.comp[c];
-                    if (cc.cm_len && cc.cm_fill != ZF_ZERO) {
-                        u32 *t = reinterpret_cast<u32 *>(sl + cc.cm_off);
-                        if (cc.cm_fill == ZF_CONST) { for (u32 i = tid; i < cc.cm_len; i += nthr) t[i] = cc.cm_fill_val; }
-                        else { const u32 *img = B.img + cc.cm_fill_val; for (u32 i = tid; i < cc.cm_len; i += nthr) t[i] = img[i % cc.cm_pat_len]; }
-                    }
-                    if (cc.a16_len && cc.a16_fill) {
-                        u16 *t = reinterpret_cast<u16 *>(sl + cc.a16_off);
-                        for (u32 i = tid; i < cc.a16_len; i += nthr) t[i] = (u16)cc.a16_fill;
-                    }
-                }
-            }
-            if (tid == 0) *misc = 0u;
-        }
+        init_slots(B, M, n, wg_slot0, nact, tid, nthr);
+        if (tid == 0) *misc = 0u;
         __threadfence();
         __syncthreads();
 
@@ -769,12 +777,469 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
     }
 }
 
+
+// ================================================================================================================
+// The DECODER of the same models: wave i = component i of the workgroup's 64 blocks (lane = block), the last wave = the
+// arithmetic decoder -- but bit-synchronous: a decoder cannot run ahead of the bit.  Per bit: every component wave sends
+// its table loads out at once (addresses depend on contexts only; an SSE takes its whole 32-entry row, the entry is picked
+// when its input is known), the predictions are then made level by level -- level 0 = components without inputs, level
+// k = 1 + the deepest input -- and handed on through LDS with one s_barrier per level; the decoder wave reads the last
+// component's prediction, decodes the bit and hands it back; every wave trains its component and moves to the next bit's
+// contexts.  Against zpq_lanes.hip (lane = component, four blocks per wave) a wave issues only its own type's code, for
+// 64 blocks, and the bit costs one trip to the tables plus the chain of levels.
+constexpr int D_P = L_DT2K + 512;                // i32 p[16][BPW]: this bit's predictions
+constexpr int D_Y = D_P + 16 * BPW * 4;          // u32 y[BPW]
+constexpr int D_ALIVE = D_Y + BPW * 4;           // u32 alive[BPW]: the block has not met its EOF flag yet
+constexpr int D_ANY = D_ALIVE + BPW * 4;         // u32: some block of the workgroup is alive
+constexpr int D_SSE = D_ANY + 16;                // per SSE component: its 32-entry row per lane (entries 0..31: the input picks 0..30 and the next), 36 words apart
+constexpr int D_SSE_BYTES = 36 * 4 * BPW;
+
+struct DStage {
+    const DBatch *B;
+    const DModel *M;
+    u8 *lds;
+    const GCfg *cfg;
+    int ci, lane, n;
+    bool active;
+    u8 *slot;
+    const u8 *src;
+    u32 nin;
+    u8 *dst;
+    u32 cap;
+    int blk;
+    u64 prof[4];                 // (-DZPG_PROF) cycles: loads in, levels, waiting for the bit, training
+};
+
+template <int TYPE>
+__device__ __forceinline__ void comp_dec(const DStage &S)
+{
+    const DModel &M = *S.M;
+    u8 *const lds = S.lds;
+    const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + L_STRETCH);
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + L_SQUASH);
+    const u8 *s_ns = lds + L_NS;
+    const u32 *s_dt = reinterpret_cast<const u32 *>(lds + L_DT);
+    const int16_t *s_dt2k = reinterpret_cast<const int16_t *>(lds + L_DT2K);
+    auto squash = [&](i32 d) -> i32 { return s_squash[min(max(wadd(d, 2047), 0), 4093)]; };
+    auto stretch = [&](i32 pr) -> i32 {
+        const u32 q = (u32)min(max(pr, 1), 32767);
+        const u32 wv = s_stretch[q >> 4];
+        const u32 ei = q < 64u ? q : (q - 32704u + 64u);
+        const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
+        const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
+        return (q < 64u || q >= 32704u) ? endv : midv;
+    };
+    (void)s_ns; (void)s_dt; (void)s_dt2k; (void)squash; (void)stretch;
+    const int ci = S.ci;
+    const GCfg &G = *S.cfg;
+    const DComp &C = M.comp[ci];
+    const i32 ca = C.a, cb = C.b, cc = C.c, climit = C.limit, cj = C.j, ck = C.k, crate = C.rate, cmask = C.mask;
+    const u32 cm_len = C.cm_len, ht_len = C.ht_len;
+    u32 *const cm = reinterpret_cast<u32 *>(S.slot + C.cm_off);
+    u8 *const ht = S.slot + C.ht_off;
+    u16 *const a16 = reinterpret_cast<u16 *>(S.slot + C.a16_off);
+    (void)ca; (void)cb; (void)cc; (void)climit; (void)cj; (void)ck; (void)crate; (void)cmask; (void)cm_len; (void)ht_len; (void)cm; (void)ht; (void)a16;
+    i32 *const s_p = reinterpret_cast<i32 *>(lds + D_P);
+    const u32 *const s_y = reinterpret_cast<const u32 *>(lds + D_Y);
+    const u32 *const s_alive = reinterpret_cast<const u32 *>(lds + D_ALIVE);
+    const u32 *const s_any = reinterpret_cast<const u32 *>(lds + D_ANY);
+    u32 *const s_row = reinterpret_cast<u32 *>(lds + D_SSE + (int)G.dslot[ci] * D_SSE_BYTES) + S.lane * 36;   // (SSE only)
+    auto pin_of = [&](const int comp) -> i32 { return s_p[comp * BPW + S.lane]; };
+    const int mylevel = G.level[ci], nlev = G.nlevels;
+    const u32 hash_steps = (u32)ci < (u32)G.hashes ? (u32)ci + 1u : 0u;
+
+    u32 prev = 0, hctx = 0;
+    i32 ma = (TYPE == ZT_MATCH) ? ca : 0, mb = (TYPE == ZT_MATCH) ? cb : 0, mc = 0, mlimit = 0;   // quirk Q17
+    u32 mpred = 0;
+    u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0, roff = 0;
+    (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mpred; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
+
+    for (;;) {
+        lds_barrier();                                           // the decoder wave has looked at the EOF flag
+        const bool alive = S.active && s_alive[S.lane] != 0;
+        if (*s_any == 0) break;
+        u32 c8 = 1, hmap4 = 1;
+#pragma unroll 1
+        for (int kb = 0; kb < 8; kb++) {
+#ifdef ZPG_PROF
+            const u64 t0 = __builtin_readcyclecounter();
+#endif
+            // ---- this bit's table entries, requested as soon as the contexts are known
+            u32 v0 = 0, v1 = 0, st = 0, idx = 0;
+            i32 wv[8], pinv[8];
+            bool row_ok = false;
+            (void)v0; (void)v1; (void)st; (void)idx; (void)wv; (void)pinv; (void)row_ok;
+            if (alive) {
+                if (TYPE == ZT_CM) {
+                    idx = (hctx ^ hmap4) & (cm_len - 1u);
+                    v0 = cm[idx];
+                } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {
+                    if (c8 == 1 || (c8 & 0xf0u) == 16u) {        // find_ht (predictor.v:495-532)
+                        const u32 cx = hctx + 16u * c8;
+                        const u32 chk = (cx >> (ca + 2)) & 255u;
+                        const u32 h0 = (cx * 16u) & (ht_len - 16u);
+                        const u32x4 A = *reinterpret_cast<const u32x4 *>(ht + h0);
+                        const u32x4 Bq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 16u));
+                        const u32x4 Cq = *reinterpret_cast<const u32x4 *>(ht + (h0 ^ 32u));
+                        const bool ma_ = (A.x & 255u) == chk, mb_ = (Bq.x & 255u) == chk, mc_ = (Cq.x & 255u) == chk;
+                        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+                        const bool va = qa <= qb && qa <= qc, vb = qb < qc;
+                        const bool hit = ma_ || mb_ || mc_;
+                        const bool ua = ma_ || (!hit && va);
+                        const bool ub = !ua && (mb_ || (!hit && vb));
+                        roff = ua ? h0 : (ub ? (h0 ^ 16u) : (h0 ^ 32u));
+                        r0 = hit ? (ua ? A.x : (ub ? Bq.x : Cq.x)) : chk;
+                        r1 = hit ? (ua ? A.y : (ub ? Bq.y : Cq.y)) : 0u;
+                        r2 = hit ? (ua ? A.z : (ub ? Bq.z : Cq.z)) : 0u;
+                        r3 = hit ? (ua ? A.w : (ub ? Bq.w : Cq.w)) : 0u;
+                    }
+                    const u32 slotn = hmap4 & 15u;
+                    const u32 dsel = (slotn & 8u) ? ((slotn & 4u) ? r3 : r2) : ((slotn & 4u) ? r1 : r0);
+                    st = (dsel >> ((slotn & 3u) * 8u)) & 255u;
+                    if (TYPE == ZT_ICM) v0 = cm[st];
+                    else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st * 2); v0 = w.x; v1 = w.y; }
+                } else if (TYPE == ZT_MATCH) {
+                    if (kb == 0 && ma != 0) mpred = ht[wsub(mlimit, mb) & (i32)(ht_len - 1)];
+                } else if (TYPE == ZT_MIX2) {
+                    idx = (hctx + (c8 & (u32)cmask)) & (u32)(cc - 1);
+                    v0 = a16[idx];
+                } else if (TYPE == ZT_MIX) {
+                    idx = (u32)(wadd((i32)hctx, (i32)c8 & cmask) & (cc - 1));
+                    const u32 *wrow = cm + (size_t)wmul((i32)idx, climit);
+#pragma unroll
+                    for (int l = 0; l < 8; l++) wv[l] = 0;
+                    auto ld = [&](const int at, const int cnt) {
+                        if (cnt >= 4) { const u32x4a t = *reinterpret_cast<const u32x4a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; wv[at + 2] = (i32)t.z; wv[at + 3] = (i32)t.w; }
+                        else if (cnt == 3) { const u32x3a t = *reinterpret_cast<const u32x3a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; wv[at + 2] = (i32)t.z; }
+                        else if (cnt == 2) { const u32x2a t = *reinterpret_cast<const u32x2a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; }
+                        else if (cnt == 1) wv[at] = (i32)wrow[at];
+                    };
+                    ld(0, climit);
+                    if (climit > 4) ld(4, climit - 4);
+                } else if (TYPE == ZT_SSE) {
+                    idx = (hctx + c8) * 32u;                     // the row of this bit context; entry = row + f(input)
+                    row_ok = (i32)idx >= 0 && idx + 32u <= cm_len;
+                    if (row_ok) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) *reinterpret_cast<u32x4 *>(s_row + 4 * q) = *reinterpret_cast<const u32x4 *>(cm + idx + 4 * q);
+                    }
+                }
+            }
+#ifdef ZPG_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const u64 t1 = __builtin_readcyclecounter();
+#endif
+            // ---- predictions, level by level
+            i32 p = 0, sse_i = 0, sse_wt = 0;
+            bool sse_ok = false;
+            (void)sse_i; (void)sse_wt; (void)sse_ok;
+            for (int lv = 0; lv < nlev; lv++) {
+                if (lv == mylevel && alive) {
+                    if (TYPE == ZT_CONST) p = (ca - 128) * 16;
+                    else if (TYPE == ZT_CM) p = stretch((i32)(v0 >> 17));
+                    else if (TYPE == ZT_ICM) p = stretch((i32)(v0 >> 8));
+                    else if (TYPE == ZT_MATCH) {
+                        if (ma == 0) p = 0;
+                        else {
+                            mc = (i32)((mpred >> (7 - kb)) & 1u);
+                            p = stretch((s_dt2k[ma & 255] * (mc * -2 + 1)) & 32767);
+                        }
+                    } else if (TYPE == ZT_AVG) p = wadd(wmul(pin_of(ca), cc), wmul(pin_of(cb), 256 - cc)) >> 8;
+                    else if (TYPE == ZT_MIX2) {
+                        pinv[0] = pin_of(cj); pinv[1] = pin_of(ck);
+                        p = clamp2k(wadd(wmul((i32)v0, pinv[0]), wmul(65536 - (i32)v0, pinv[1])) >> 16);
+                    } else if (TYPE == ZT_ISSE) {
+                        pinv[0] = pin_of(cb);
+                        p = clamp2k(wadd(wmul((i32)v0, pinv[0]), wmul((i32)v1, 64)) >> 16);
+                    } else if (TYPE == ZT_MIX) {
+                        i32 sum = 0;
+#pragma unroll
+                        for (int l = 0; l < 8; l++) { pinv[l] = l < climit ? pin_of(cb + l) : 0; sum = wadd(sum, wmul(wv[l] >> 8, pinv[l])); }
+                        p = clamp2k(sum >> 8);
+                    } else if (TYPE == ZT_SSE) {
+                        i32 pq = wadd(pin_of(cb), 992);
+                        pq = min(max(pq, 0), 1983);
+                        sse_wt = pq & 63;
+                        pq >>= 6;
+                        sse_i = wadd((i32)idx, pq);
+                        sse_ok = sse_i >= 0 && wadd(sse_i, 1) < (i32)cm_len;
+                        if (sse_ok) {                            // (then the row is in: idx >= 0 and idx + 32 <= cm_len)
+                            v0 = s_row[pq]; v1 = s_row[pq + 1];
+                            p = stretch(wadd(wmul((i32)(v0 >> 10), 64 - sse_wt), wmul((i32)(v1 >> 10), sse_wt)) >> 13);
+                        } else p = 0;
+                    }
+                    s_p[ci * BPW + S.lane] = p;
+                }
+                lds_barrier();
+            }
+#ifdef ZPG_PROF
+            const u64 t2 = __builtin_readcyclecounter();
+#endif
+            lds_barrier();                                       // the decoder wave has the bit
+            const i32 y = (i32)(s_y[S.lane] & 1u);
+#ifdef ZPG_PROF
+            const u64 t3 = __builtin_readcyclecounter();
+#endif
+            // ---- train (predictor.v:670-805)
+            if (alive) {
+                const i32 t32767 = y ? 32767 : 0;
+                if (TYPE == ZT_CM) {
+                    const i32 count = (i32)(v0 & 0x3ffu);
+                    const i32 err = t32767 - (i32)(v0 >> 17);
+                    const i32 upd = wmul(err, (i32)s_dt[count]) & -1024;
+                    cm[idx] = (u32)wadd(wadd((i32)v0, upd), count < climit ? 1 : 0);
+                } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {
+                    if (TYPE == ZT_ICM) cm[st] = (u32)wadd((i32)v0, (t32767 - (i32)(v0 >> 8)) >> 2);
+                    else {
+                        const i32 err = t32767 - squash(p);
+                        const i32 n0 = clamp512k(wadd((i32)v0, wadd(wmul(err, pinv[0]), 1 << 12) >> 13));
+                        const i32 n1 = clamp512k(wadd((i32)v1, (err + 16) >> 5));
+                        *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2((u32)n0, (u32)n1);
+                    }
+                    const u32 slotn = hmap4 & 15u, sh = (slotn & 3u) * 8u;
+                    const u32 nsv = s_ns[st * 4 + (u32)y];
+                    const u32 dsel = (slotn & 8u) ? ((slotn & 4u) ? r3 : r2) : ((slotn & 4u) ? r1 : r0);
+                    const u32 ins = (dsel & ~(255u << sh)) | (nsv << sh);
+                    r0 = (slotn < 4u) ? ins : r0;
+                    r1 = (slotn >= 4u && slotn < 8u) ? ins : r1;
+                    r2 = (slotn >= 8u && slotn < 12u) ? ins : r2;
+                    r3 = (slotn >= 12u) ? ins : r3;
+                    if ((kb & 3) == 3) *reinterpret_cast<u32x4 *>(ht + roff) = u32x4{r0, r1, r2, r3};
+                } else if (TYPE == ZT_MATCH) {
+                    if (mc != y) ma = 0;
+                } else if (TYPE == ZT_MIX2) {
+                    const i32 err = wmul(t32767 - squash(p), crate) >> 5;
+                    i32 wn = wadd((i32)v0, wadd(wmul(err, wsub(pinv[0], pinv[1])), 1 << 12) >> 13);
+                    wn = min(max(wn, 0), 65535);
+                    a16[idx] = (u16)wn;
+                } else if (TYPE == ZT_MIX) {
+                    const i32 err = wmul(t32767 - squash(p), crate) >> 4;
+#pragma unroll
+                    for (int l = 0; l < 8; l++) wv[l] = clamp512k(wadd(wv[l], wadd(wmul(err, pinv[l]), 1 << 12) >> 13));
+                    u32 *wrow = cm + (size_t)wmul((i32)idx, climit);
+                    auto stw = [&](const int at, const int cnt) {
+                        if (cnt >= 4) *reinterpret_cast<u32x4a *>(wrow + at) = u32x4a{(u32)wv[at], (u32)wv[at + 1], (u32)wv[at + 2], (u32)wv[at + 3]};
+                        else if (cnt == 3) *reinterpret_cast<u32x3a *>(wrow + at) = u32x3a{(u32)wv[at], (u32)wv[at + 1], (u32)wv[at + 2]};
+                        else if (cnt == 2) *reinterpret_cast<u32x2a *>(wrow + at) = u32x2a{(u32)wv[at], (u32)wv[at + 1]};
+                        else if (cnt == 1) wrow[at] = (u32)wv[at];
+                    };
+                    stw(0, climit);
+                    if (climit > 4) stw(4, climit - 4);
+                } else if (TYPE == ZT_SSE) {
+                    const u32 iu = ((u32)sse_i + (u32)(sse_wt >> 5)) & (cm_len - 1u);
+                    u32 v;
+                    if (sse_ok && iu == (u32)sse_i) v = v0;
+                    else if (sse_ok && iu == (u32)sse_i + 1u) v = v1;
+                    else v = cm[iu];
+                    const i32 err = t32767 - (i32)(v >> 17);
+                    const i32 count = (i32)v & 1023;
+                    if (count < climit) v = (u32)wadd(wadd((i32)v, wadd(wmul(err, climit - count), 1 << 12) >> 13), 1);
+                    cm[iu] = v;
+                }
+            }
+            c8 = (c8 << 1) | (u32)y;
+            if (c8 >= 256u) { }
+            else if (c8 >= 16u && c8 < 32u) hmap4 = ((hmap4 & 0xfu) << 5) | ((u32)y << 4) | 1u;
+            else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
+#ifdef ZPG_PROF
+            {
+                const u64 t4 = __builtin_readcyclecounter();
+                u64 *pr = const_cast<DStage &>(S).prof;
+                pr[0] += t1 - t0; pr[1] += t2 - t1; pr[2] += t3 - t2; pr[3] += t4 - t3;
+            }
+#endif
+        }
+        const u32 byte = c8 - 256u;
+        if (TYPE == ZT_MATCH && alive) {                         // the byte boundary of predictor.v:722-741
+            const i32 mask = (i32)(ht_len - 1);
+            ht[mlimit & mask] = (u8)byte;
+            mlimit = wadd(mlimit, 1) & mask;
+            const i32 cmi = (i32)hctx & (i32)(cm_len - 1);
+            if (ma == 0) {
+                mb = wsub(mlimit, (i32)cm[cmi]);
+                if ((mb & mask) != 0) {
+                    while (ma < 255) {
+                        u32 x[4], z[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            x[t] = ht[wsub(wsub(mlimit, ma), 1 + t) & mask];
+                            z[t] = ht[wsub(wsub(wsub(mlimit, ma), mb), 1 + t) & mask];
+                        }
+                        int eq = 0;
+#pragma unroll
+                        for (int t = 3; t >= 0; t--) eq = x[t] == z[t] ? eq + 1 : 0;
+                        ma = min(ma + eq, 255);
+                        if (eq < 4) break;
+                    }
+                }
+            } else if (ma < 255) ma++;
+            cm[cmi] = (u32)mlimit;
+        }
+        {
+            u32 a = byte;
+            for (u32 k = 0; k < hash_steps; k++) a = (a + prev + 512u) * 773u;
+            hctx = hash_steps ? a : 0u;
+            prev = byte;
+        }
+    }
+}
+
+// the decoder wave (decoder.v): EOF flag, eight bits per byte from the last component's predictions, output bytes
+__device__ __forceinline__ void coder_dec(const DStage &S)
+{
+    const DBatch &B = *S.B;
+    u8 *const lds = S.lds;
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + L_SQUASH);
+    const GCfg &G = *S.cfg;
+    const i32 *const s_p = reinterpret_cast<const i32 *>(lds + D_P);
+    u32 *const s_y = reinterpret_cast<u32 *>(lds + D_Y);
+    u32 *const s_alive = reinterpret_cast<u32 *>(lds + D_ALIVE);
+    u32 *const s_any = reinterpret_cast<u32 *>(lds + D_ANY);
+    const int n = S.n, nlev = G.nlevels;
+    const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
+    const u8 *const src = S.src;
+    const u32 nin = S.nin;
+    // the coded stream: the aligned dword under the read position and the one after it, asked for four bytes early
+    u32 ipos = 0, w0 = 0, w1 = 0;
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(src);
+    auto dword_at = [&](const uintptr_t a) -> u32 {              // a: aligned; 0 when the dword holds no byte of the stream
+        return (a < s0 + nin && a + 4 > s0) ? *reinterpret_cast<const u32 *>(a) : 0u;
+    };
+    if (S.active && nin) { w0 = dword_at(s0 & ~(uintptr_t)3); w1 = dword_at((s0 & ~(uintptr_t)3) + 4); }
+    auto next_byte = [&]() -> u32 {
+        const uintptr_t a = s0 + ipos;
+        const u32 c = ipos < nin ? (w0 >> (8u * (u32)(a & 3))) & 255u : 0u;
+        if (ipos < nin) {
+            ipos++;
+            if (((a + 1) & 3) == 0) { w0 = w1; w1 = dword_at((a + 1) + 4); }
+        }
+        return c;
+    };
+    u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, first = 0xFFFFFFFFu;
+    bool got_first = false, alive = S.active;
+    if (alive) for (int k = 0; k < 4; k++) code = (code << 8) | next_byte();
+    auto shift_in = [&]() {
+        while ((high ^ low) < 0x1000000u) {
+            low <<= 8; high = (high << 8) | 255u; low = low ? low : 1u;
+            code = (code << 8) | next_byte();
+        }
+    };
+    for (;;) {
+        if (alive) {                                             // the EOF flag: decode(0) (decoder.v)
+            if (code <= low) { alive = false; high = low; }
+            else low += 1;
+            shift_in();
+        }
+        s_alive[S.lane] = alive ? 1u : 0u;
+        const bool any = __any(alive ? 1 : 0) != 0;
+        if (S.lane == 0) *s_any = any ? 1u : 0u;
+        lds_barrier();
+        if (!any) break;
+        u32 c8 = 1;
+#pragma unroll 1
+        for (int kb = 0; kb < 8; kb++) {
+            for (int lv = 0; lv < nlev; lv++) lds_barrier();
+            u32 y = 0;
+            if (alive) {
+                const u32 sq = s_squash[min(max(s_p[(n - 1) * BPW + S.lane] + 2047, 0), 4093)];
+                const u32 p16 = sq * 2u + 1u;
+                const u32 mid = low + mul_shr16(high - low, p16);
+                y = code <= mid ? 1u : 0u;
+                high = y ? mid : high;
+                low = y ? low : mid + 1;
+                shift_in();
+            }
+            s_y[S.lane] = y;
+            c8 = (c8 << 1) | y;
+            lds_barrier();
+        }
+        if (alive) {
+            const u32 byte = c8 - 256u;
+            if (pp && !got_first) { first = byte; got_first = true; }
+            else {
+                if (opos < S.cap) S.dst[opos] = (u8)byte;
+                opos++;
+                if (opos > S.cap) alive = false;
+            }
+        }
+    }
+    if (S.active) {
+        B.out_len[S.blk] = opos;
+        B.status[S.blk] = opos > S.cap ? ZPQ_E_OVERFLOW : ZPQ_OK;
+        if (B.consumed) B.consumed[S.blk] = ipos;
+        if (B.final_code) B.final_code[S.blk] = code;
+        if (B.first_byte) B.first_byte[S.blk] = first;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_gdec(const DBatch B, const GCfg cfg)
+{
+    extern __shared__ __align__(16) u8 lds[];
+    const DModel &M = *B.model;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    {
+        u32 *st = reinterpret_cast<u32 *>(lds + L_STRETCH);
+        for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
+        u16 *sq = reinterpret_cast<u16 *>(lds + L_SQUASH);
+        for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[i];
+        for (int i = tid; i < 1024; i += nthr) lds[L_NS + i] = B.ns[i];
+        u32 *dt = reinterpret_cast<u32 *>(lds + L_DT);
+        for (int i = tid; i < 1024; i += nthr) dt[i] = B.dt[i];
+        int16_t *d2 = reinterpret_cast<int16_t *>(lds + L_DT2K);
+        for (int i = tid; i < 256; i += nthr) d2[i] = B.dt2k[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = cfg.n;
+    const int wg_slot0 = blockIdx.x * cfg.bpw;
+    const int nslots = B.nslots;
+    const int slot_id = wg_slot0 + lane;
+    const bool lane_on = lane < cfg.bpw && slot_id < nslots;
+    u8 *const slot = B.slots + (u64)(lane_on ? slot_id : wg_slot0) * M.slot_bytes;
+    const int wg_slots = min(cfg.bpw, nslots - wg_slot0);
+
+    for (int base = wg_slot0; base < B.nblocks; base += nslots) {
+        const int blk = base + lane;
+        const bool active = lane_on && blk < B.nblocks;
+        const int nact = min(wg_slots, B.nblocks - base);
+        init_slots(B, M, n, wg_slot0, nact, tid, nthr);
+        __threadfence();
+        __syncthreads();
+        DStage S;
+        S.B = &B; S.M = &M; S.lds = lds; S.cfg = &cfg; S.ci = wave; S.lane = lane; S.n = n; S.active = active; S.slot = slot; S.blk = blk;
+        S.src = active ? B.in + B.in_off[blk] : B.in;
+        S.nin = active ? (u32)(B.in_off[blk + 1] - B.in_off[blk]) : 0u;
+        S.dst = active ? B.out + B.out_off[blk] : B.out;
+        S.cap = active ? (u32)(B.out_off[blk + 1] - B.out_off[blk]) : 0u;
+        S.prof[0] = S.prof[1] = S.prof[2] = S.prof[3] = 0;
+        if (wave < n) {
+            switch (M.comp[wave].type) {                         // uniform per wave
+            case ZT_CONST: comp_dec<ZT_CONST>(S); break;
+            case ZT_CM: comp_dec<ZT_CM>(S); break;
+            case ZT_ICM: comp_dec<ZT_ICM>(S); break;
+            case ZT_MATCH: comp_dec<ZT_MATCH>(S); break;
+            case ZT_AVG: comp_dec<ZT_AVG>(S); break;
+            case ZT_MIX2: comp_dec<ZT_MIX2>(S); break;
+            case ZT_MIX: comp_dec<ZT_MIX>(S); break;
+            case ZT_ISSE: comp_dec<ZT_ISSE>(S); break;
+            default: comp_dec<ZT_SSE>(S); break;
+            }
+        } else coder_dec(S);
+#ifdef ZPG_PROF
+        if (blockIdx.x == 0 && lane == 0 && wave < n)
+            printf("gdec wave %d type %d level %d: loads %llu, levels %llu, bit %llu, train %llu cycles\n", wave, M.comp[wave].type, (int)cfg.level[wave],
+                   (unsigned long long)S.prof[0], (unsigned long long)S.prof[1], (unsigned long long)S.prof[2], (unsigned long long)S.prof[3]);
+#endif
+        __syncthreads();
+    }
+}
+
 }  // namespace zpqg
 
 // ------------------------------------------------------------------ host side
 // The pipeline takes a model when every component is one of the nine types, names only EARLIER components as inputs, the
 // HCOMP program is the shipped hash chain with a hash per component, and the rings fit the LDS.
-static bool gpipe_cfg(const DModel *M, zpqg::GCfg *cfg, size_t *lds_bytes)
+static bool gpipe_cfg(const DModel *M, zpqg::GCfg *cfg, size_t *lds_bytes, size_t *dec_lds = nullptr)
 {
     const int n = M->n;
     if (n < 1 || n > 15) return false;
@@ -808,6 +1273,24 @@ static bool gpipe_cfg(const DModel *M, zpqg::GCfg *cfg, size_t *lds_bytes)
         total += depth;
     }
     cfg->n = n; cfg->ring = total; cfg->hashes = hashes;
+    int nsse = 0, nlev = 1;
+    for (int i = 0; i < n; i++) {                                // (inputs are earlier components: one pass)
+        const DComp &c = M->comp[i];
+        int lv = 0;
+        auto dep = [&](int j) { if (cfg->level[j] + 1 > lv) lv = cfg->level[j] + 1; };
+        switch (c.type) {
+        case ZT_AVG: dep(c.a); dep(c.b); break;
+        case ZT_MIX2: dep(c.j); dep(c.k); break;
+        case ZT_MIX: for (int l = 0; l < c.limit; l++) dep(c.b + l); break;
+        case ZT_ISSE: dep(c.b); break;
+        case ZT_SSE: dep(c.b); cfg->dslot[i] = (uint8_t)nsse++; break;
+        default: break;
+        }
+        cfg->level[i] = (uint8_t)lv;
+        if (lv + 1 > nlev) nlev = lv + 1;
+    }
+    cfg->nlevels = nlev;
+    if (dec_lds) *dec_lds = (size_t)zpqg::D_SSE + (size_t)nsse * zpqg::D_SSE_BYTES;
     *lds_bytes = (size_t)zpqg::L_LINK + (size_t)total * zpqg::BPW * 16 + 16;
     return *lds_bytes <= 160 * 1024;
 }
@@ -847,5 +1330,52 @@ extern "C" int zpq_launch_gpipe(const DBatch *B, const DModel *hostM, int nslots
         (void)hipFuncSetAttribute((const void *)zpqg::k_gpipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(zpqg::k_gpipe<true>, dim3(nwg), dim3(64 * (cfg.n + 1)), lds, stream, *B, cfg);
     }
+    return ZPQ_OK;
+}
+
+// ---- the decoder (k_gdec).  ZPQ_DEC_GPIPE=0 keeps general models' decoding on zpq_lanes.hip.
+extern "C" int zpq_gdec_applies(const DModel *M)
+{
+    const char *ev = getenv("ZPQ_DEC_GPIPE");
+    if (ev && atoi(ev) == 0) return 0;
+    zpqg::GCfg cfg;
+    size_t lds = 0, dlds = 0;
+    return gpipe_cfg(M, &cfg, &lds, &dlds) && dlds <= 160 * 1024 ? 1 : 0;
+}
+
+static int gdec_wgs_per_cu(const zpqg::GCfg &cfg, size_t dlds)
+{
+    const int wgs = (int)((160 * 1024) / dlds);
+    const int by_waves = 20 / (cfg.n + 1);                     // 83 VGPRs: five waves per SIMD
+    const int w = wgs < by_waves ? wgs : by_waves;
+    return w < 1 ? 1 : w;
+}
+
+extern "C" int zpq_gdec_blocks_per_cu(const DModel *M)
+{
+    zpqg::GCfg cfg;
+    size_t lds = 0, dlds = 0;
+    if (!gpipe_cfg(M, &cfg, &lds, &dlds)) return 0;
+    return gdec_wgs_per_cu(cfg, dlds) * zpqg::BPW;
+}
+
+extern "C" int zpq_launch_gdec(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream)
+{
+    zpqg::GCfg cfg;
+    size_t lds = 0, dlds = 0;
+    if (!gpipe_cfg(hostM, &cfg, &lds, &dlds)) return ZPQ_E_INTERNAL;
+    // The decoder is bound by the latency of a bit's trip to the tables, not by instruction issue: a batch that does not fill
+    // every workgroup slot of the chip with 64 blocks per workgroup is spread over more workgroups of 32 or 16 lanes.
+    static int cus = 0;
+    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus < 1) cus = 256; }
+    const char *ev = getenv("ZPQ_GDEC_BPW");                     // tuning / test knob
+    int bpw = zpqg::BPW;
+    const int want = cus * gdec_wgs_per_cu(cfg, dlds);
+    while (bpw > 16 && (nslots + bpw - 1) / bpw < want) bpw /= 2;
+    if (ev && (atoi(ev) == 16 || atoi(ev) == 32 || atoi(ev) == 64)) bpw = atoi(ev);
+    cfg.bpw = bpw;
+    const int nwg = (nslots + bpw - 1) / bpw;
+    (void)hipFuncSetAttribute((const void *)zpqg::k_gdec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(zpqg::k_gdec, dim3(nwg), dim3(64 * (cfg.n + 1)), dlds, stream, *B, cfg);
     return ZPQ_OK;
 }
