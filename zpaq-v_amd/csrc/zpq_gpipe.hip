@@ -363,14 +363,11 @@ __device__ __forceinline__ void comp_stage(const Stage &S)
                             const u32 *wrow = cm + (size_t)wmul((i32)cx[q], climit);
 #pragma unroll
                             for (int l = 0; l < 8; l++) wv[q][l] = 0;
-                            auto ld = [&](const int at, const int cnt) {
-                                if (cnt >= 4) { const u32x4a t = *reinterpret_cast<const u32x4a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; wv[q][at + 2] = (i32)t.z; wv[q][at + 3] = (i32)t.w; }
-                                else if (cnt == 3) { const u32x3a t = *reinterpret_cast<const u32x3a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; wv[q][at + 2] = (i32)t.z; }
-                                else if (cnt == 2) { const u32x2a t = *reinterpret_cast<const u32x2a *>(wrow + at); wv[q][at] = (i32)t.x; wv[q][at + 1] = (i32)t.y; }
-                                else if (cnt == 1) wv[q][at] = (i32)wrow[at];
-                            };
-                            ld(0, climit);
-                            if (climit > 4) ld(4, climit - 4);
+                            {   // eight words whatever the row's length (no branch around a load; see comp_dec's load_row)
+                                const u32x4a lo = *reinterpret_cast<const u32x4a *>(wrow), hi = *reinterpret_cast<const u32x4a *>(wrow + 4);
+                                wv[q][0] = (i32)lo.x; wv[q][1] = (i32)lo.y; wv[q][2] = (i32)lo.z; wv[q][3] = (i32)lo.w;
+                                wv[q][4] = (i32)hi.x; wv[q][5] = (i32)hi.y; wv[q][6] = (i32)hi.z; wv[q][7] = (i32)hi.w;
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
@@ -714,7 +711,7 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
         for (int i = tid; i < 256; i += nthr) d2[i] = B.dt2k[i];
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform, and known to the compiler as such: component constants in SGPRs, scalar branches)
     const int n = cfg.n;
     const int wg_slot0 = blockIdx.x * BPW;
     const int nslots = B.nslots;
@@ -845,6 +842,15 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
     const u32 *const s_any = reinterpret_cast<const u32 *>(lds + D_ANY);
     u32 *const s_row = reinterpret_cast<u32 *>(lds + D_SSE + (int)G.dslot[ci] * D_SSE_BYTES) + S.lane * 36;   // (SSE only)
     auto pin_of = [&](const int comp) -> i32 { return s_p[comp * BPW + S.lane]; };
+    // a MIX row of climit <= 8 weights, read as eight words whatever its length: no branch around a load (the compiler waits for
+    // a load at the join behind it), words past the row are multiplied by inputs that are 0 and never stored; the slot pool
+    // ends in 256 spare bytes for the last row of the last table
+    auto load_row = [&](const u32 *wrow, i32 (&w)[8]) {
+        const u32x4a lo = *reinterpret_cast<const u32x4a *>(wrow), hi = *reinterpret_cast<const u32x4a *>(wrow + 4);
+        w[0] = (i32)lo.x; w[1] = (i32)lo.y; w[2] = (i32)lo.z; w[3] = (i32)lo.w;
+        w[4] = (i32)hi.x; w[5] = (i32)hi.y; w[6] = (i32)hi.z; w[7] = (i32)hi.w;
+    };
+    (void)load_row;
     const int mylevel = G.level[ci], nlev = G.nlevels;
     const u32 hash_steps = (u32)ci < (u32)G.hashes ? (u32)ci + 1u : 0u;
 
@@ -853,6 +859,22 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
     u32 mpred = 0;
     u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0, roff = 0;
     (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mpred; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
+    // Inside a nibble the NEXT bit's contexts are known now but for this bit: its table entries are asked for under both values
+    // (CM, MIX2, MIX: neighbouring entries / rows; ICM, ISSE: the two states the nibble's row holds for them) while this bit
+    // is still being predicted, and picked when the bit is known.  An entry that this bit's training then rewrites is taken from
+    // the training (tr_*), not from the load that went out before it.
+    constexpr bool SPEC = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX || TYPE == ZT_SSE;
+    constexpr bool FWD = SPEC && TYPE != ZT_SSE;                 // (an SSE trains its CURRENT row; the next bit's row is patched in LDS if ever hit)
+    bool spec = false;
+    u32 sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0, tr_a = 0xFFFFFFFFu, tr0 = 0, tr1 = 0, yprev = 0;
+    u32 nx0 = 0, nx1 = 0;                                        // ... picked as soon as the bit is known, BEFORE this bit's stores go out:
+    i32 swa[8], swb[8], trw[8], nxw[8];                          // a wait placed behind the stores would wait for their acknowledgement too
+    (void)nx0; (void)nx1; (void)nxw;
+    u32x4 ra[8], rb[8];                                          // SSE: the next bit's two candidate rows
+    bool sok0 = false, sok1 = false, nrow_ok = false;
+    u32 nrow = 0;
+    (void)ra; (void)rb; (void)sok0; (void)sok1; (void)nrow_ok; (void)nrow;
+    (void)spec; (void)sa0; (void)sa1; (void)sb0; (void)sb1; (void)tr_a; (void)tr0; (void)tr1; (void)yprev; (void)swa; (void)swb; (void)trw;
 
     for (;;) {
         lds_barrier();                                           // the decoder wave has looked at the EOF flag
@@ -872,7 +894,7 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
             if (alive) {
                 if (TYPE == ZT_CM) {
                     idx = (hctx ^ hmap4) & (cm_len - 1u);
-                    v0 = cm[idx];
+                    if (!spec) nx0 = cm[idx];
                 } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {
                     if (c8 == 1 || (c8 & 0xf0u) == 16u) {        // find_ht (predictor.v:495-532)
                         const u32 cx = hctx + 16u * c8;
@@ -896,38 +918,71 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
                     const u32 slotn = hmap4 & 15u;
                     const u32 dsel = (slotn & 8u) ? ((slotn & 4u) ? r3 : r2) : ((slotn & 4u) ? r1 : r0);
                     st = (dsel >> ((slotn & 3u) * 8u)) & 255u;
-                    if (TYPE == ZT_ICM) v0 = cm[st];
-                    else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st * 2); v0 = w.x; v1 = w.y; }
+                    idx = st;
+                    if (!spec) {
+                        if (TYPE == ZT_ICM) nx0 = cm[st];
+                        else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st * 2); nx0 = w.x; nx1 = w.y; }
+                    }
                 } else if (TYPE == ZT_MATCH) {
                     if (kb == 0 && ma != 0) mpred = ht[wsub(mlimit, mb) & (i32)(ht_len - 1)];
                 } else if (TYPE == ZT_MIX2) {
                     idx = (hctx + (c8 & (u32)cmask)) & (u32)(cc - 1);
-                    v0 = a16[idx];
+                    if (!spec) nx0 = a16[idx];
                 } else if (TYPE == ZT_MIX) {
                     idx = (u32)(wadd((i32)hctx, (i32)c8 & cmask) & (cc - 1));
-                    const u32 *wrow = cm + (size_t)wmul((i32)idx, climit);
-#pragma unroll
-                    for (int l = 0; l < 8; l++) wv[l] = 0;
-                    auto ld = [&](const int at, const int cnt) {
-                        if (cnt >= 4) { const u32x4a t = *reinterpret_cast<const u32x4a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; wv[at + 2] = (i32)t.z; wv[at + 3] = (i32)t.w; }
-                        else if (cnt == 3) { const u32x3a t = *reinterpret_cast<const u32x3a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; wv[at + 2] = (i32)t.z; }
-                        else if (cnt == 2) { const u32x2a t = *reinterpret_cast<const u32x2a *>(wrow + at); wv[at] = (i32)t.x; wv[at + 1] = (i32)t.y; }
-                        else if (cnt == 1) wv[at] = (i32)wrow[at];
-                    };
-                    ld(0, climit);
-                    if (climit > 4) ld(4, climit - 4);
+                    if (!spec) load_row(cm + (size_t)wmul((i32)idx, climit), nxw);
                 } else if (TYPE == ZT_SSE) {
                     idx = (hctx + c8) * 32u;                     // the row of this bit context; entry = row + f(input)
-                    row_ok = (i32)idx >= 0 && idx + 32u <= cm_len;
-                    if (row_ok) {
+                    if (spec) row_ok = nrow_ok;                  // (the row was put into LDS when the last bit became known)
+                    else {
+                        row_ok = (i32)idx >= 0 && idx + 32u <= cm_len;
+                        if (row_ok) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) *reinterpret_cast<u32x4 *>(s_row + 4 * q) = *reinterpret_cast<const u32x4 *>(cm + idx + 4 * q);
+                            for (int q = 0; q < 8; q++) *reinterpret_cast<u32x4 *>(s_row + 4 * q) = *reinterpret_cast<const u32x4 *>(cm + idx + 4 * q);
+                        }
                     }
                 }
             }
+            // ---- the next bit's entries under both values of this bit
+            // (a bit-history row changes with the nibble; everything else only needs the byte to go on: hctx stays)
+            const bool spec_next = SPEC && alive && kb != 7 && !((TYPE == ZT_ICM || TYPE == ZT_ISSE) && kb == 3);
+            if (spec_next) {
+                const u32 hm0 = kb == 3 ? (((hmap4 & 0xfu) << 5) | 1u) : ((hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u) & 0xfu));
+                const u32 hm1 = kb == 3 ? (((hmap4 & 0xfu) << 5) | 17u) : ((hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + 1u) & 0xfu));
+                const u32 c80 = c8 << 1, c81 = (c8 << 1) | 1u;
+                (void)hm0; (void)hm1; (void)c80; (void)c81;
+                if (TYPE == ZT_CM) {
+                    sa0 = cm[(hctx ^ hm0) & (cm_len - 1u)];
+                    sb0 = cm[(hctx ^ hm1) & (cm_len - 1u)];
+                } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {
+                    // (a 64-bit shift, not a four-way select: two of those in a row the compiler turns into a stack array)
+                    const u64 rlo = (u64)r0 | ((u64)r1 << 32), rhi = (u64)r2 | ((u64)r3 << 32);
+                    auto state_at = [&](const u32 slotn) -> u32 { return (u32)(((slotn & 8u) ? rhi : rlo) >> ((slotn & 7u) * 8u)) & 255u; };
+                    const u32 st0 = state_at(hm0 & 15u), st1 = state_at(hm1 & 15u);
+                    if (TYPE == ZT_ICM) { sa0 = cm[st0]; sb0 = cm[st1]; }
+                    else {
+                        const uint2 wa = *reinterpret_cast<const uint2 *>(cm + st0 * 2), wb = *reinterpret_cast<const uint2 *>(cm + st1 * 2);
+                        sa0 = wa.x; sa1 = wa.y; sb0 = wb.x; sb1 = wb.y;
+                    }
+                } else if (TYPE == ZT_MIX2) {
+                    sa0 = a16[(hctx + (c80 & (u32)cmask)) & (u32)(cc - 1)];
+                    sb0 = a16[(hctx + (c81 & (u32)cmask)) & (u32)(cc - 1)];
+                } else if (TYPE == ZT_MIX) {
+                    load_row(cm + (size_t)wmul(wadd((i32)hctx, (i32)c80 & cmask) & (cc - 1), climit), swa);
+                    load_row(cm + (size_t)wmul(wadd((i32)hctx, (i32)c81 & cmask) & (cc - 1), climit), swb);
+                } else if (TYPE == ZT_SSE) {
+                    const u32 i0 = (hctx + c80) * 32u, i1 = (hctx + c81) * 32u;
+                    sok0 = (i32)i0 >= 0 && i0 + 32u <= cm_len;
+                    sok1 = (i32)i1 >= 0 && i1 + 32u <= cm_len;
+                    const u32 j0 = sok0 ? i0 : 0u, j1 = sok1 ? i1 : 0u;     // (no branch around a load: a row outside the table reads row 0, unused)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) ra[q] = *reinterpret_cast<const u32x4 *>(cm + j0 + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) rb[q] = *reinterpret_cast<const u32x4 *>(cm + j1 + 4 * q);
+                }
+            }
 #ifdef ZPG_PROF
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const u64 t1 = __builtin_readcyclecounter();
+            const u64 t1 = __builtin_readcyclecounter();         // (loads issued, not waited for)
 #endif
             // ---- predictions, level by level
             i32 p = 0, sse_i = 0, sse_wt = 0;
@@ -935,6 +990,14 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
             (void)sse_i; (void)sse_wt; (void)sse_ok;
             for (int lv = 0; lv < nlev; lv++) {
                 if (lv == mylevel && alive) {
+                    if (FWD) {                                   // the entry as it stands now: what came in, or what the last bit's training left there
+                        const bool fwd = idx == tr_a;
+                        v0 = fwd ? tr0 : nx0; v1 = fwd ? tr1 : nx1;
+                        if (TYPE == ZT_MIX) {
+#pragma unroll
+                            for (int l = 0; l < 8; l++) wv[l] = fwd ? trw[l] : nxw[l];
+                        }
+                    }
                     if (TYPE == ZT_CONST) p = (ca - 128) * 16;
                     else if (TYPE == ZT_CM) p = stretch((i32)(v0 >> 17));
                     else if (TYPE == ZT_ICM) p = stretch((i32)(v0 >> 8));
@@ -980,6 +1043,21 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
 #ifdef ZPG_PROF
             const u64 t3 = __builtin_readcyclecounter();
 #endif
+            if (spec_next) {
+                nx0 = y ? sb0 : sa0; nx1 = y ? sb1 : sa1;
+                if (TYPE == ZT_MIX) {
+#pragma unroll
+                    for (int l = 0; l < 8; l++) nxw[l] = y ? swb[l] : swa[l];
+                }
+                if (TYPE == ZT_SSE) {                            // (this bit's entries are in v0 / v1 already: the LDS row is free)
+                    nrow_ok = y ? sok1 : sok0;
+                    nrow = (hctx + ((c8 << 1) | (u32)y)) * 32u;
+                    if (nrow_ok) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) *reinterpret_cast<u32x4 *>(s_row + 4 * q) = y ? rb[q] : ra[q];
+                    }
+                }
+            }
             // ---- train (predictor.v:670-805)
             if (alive) {
                 const i32 t32767 = y ? 32767 : 0;
@@ -987,14 +1065,16 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
                     const i32 count = (i32)(v0 & 0x3ffu);
                     const i32 err = t32767 - (i32)(v0 >> 17);
                     const i32 upd = wmul(err, (i32)s_dt[count]) & -1024;
-                    cm[idx] = (u32)wadd(wadd((i32)v0, upd), count < climit ? 1 : 0);
+                    tr_a = idx; tr0 = (u32)wadd(wadd((i32)v0, upd), count < climit ? 1 : 0);
+                    cm[idx] = tr0;
                 } else if (TYPE == ZT_ICM || TYPE == ZT_ISSE) {
-                    if (TYPE == ZT_ICM) cm[st] = (u32)wadd((i32)v0, (t32767 - (i32)(v0 >> 8)) >> 2);
+                    tr_a = st;
+                    if (TYPE == ZT_ICM) { tr0 = (u32)wadd((i32)v0, (t32767 - (i32)(v0 >> 8)) >> 2); cm[st] = tr0; }
                     else {
                         const i32 err = t32767 - squash(p);
-                        const i32 n0 = clamp512k(wadd((i32)v0, wadd(wmul(err, pinv[0]), 1 << 12) >> 13));
-                        const i32 n1 = clamp512k(wadd((i32)v1, (err + 16) >> 5));
-                        *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2((u32)n0, (u32)n1);
+                        tr0 = (u32)clamp512k(wadd((i32)v0, wadd(wmul(err, pinv[0]), 1 << 12) >> 13));
+                        tr1 = (u32)clamp512k(wadd((i32)v1, (err + 16) >> 5));
+                        *reinterpret_cast<uint2 *>(cm + st * 2) = make_uint2(tr0, tr1);
                     }
                     const u32 slotn = hmap4 & 15u, sh = (slotn & 3u) * 8u;
                     const u32 nsv = s_ns[st * 4 + (u32)y];
@@ -1011,11 +1091,13 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
                     const i32 err = wmul(t32767 - squash(p), crate) >> 5;
                     i32 wn = wadd((i32)v0, wadd(wmul(err, wsub(pinv[0], pinv[1])), 1 << 12) >> 13);
                     wn = min(max(wn, 0), 65535);
+                    tr_a = idx; tr0 = (u32)wn;
                     a16[idx] = (u16)wn;
                 } else if (TYPE == ZT_MIX) {
                     const i32 err = wmul(t32767 - squash(p), crate) >> 4;
 #pragma unroll
-                    for (int l = 0; l < 8; l++) wv[l] = clamp512k(wadd(wv[l], wadd(wmul(err, pinv[l]), 1 << 12) >> 13));
+                    for (int l = 0; l < 8; l++) { wv[l] = clamp512k(wadd(wv[l], wadd(wmul(err, pinv[l]), 1 << 12) >> 13)); trw[l] = wv[l]; }
+                    tr_a = idx;
                     u32 *wrow = cm + (size_t)wmul((i32)idx, climit);
                     auto stw = [&](const int at, const int cnt) {
                         if (cnt >= 4) *reinterpret_cast<u32x4a *>(wrow + at) = u32x4a{(u32)wv[at], (u32)wv[at + 1], (u32)wv[at + 2], (u32)wv[at + 3]};
@@ -1035,12 +1117,15 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
                     const i32 count = (i32)v & 1023;
                     if (count < climit) v = (u32)wadd(wadd((i32)v, wadd(wmul(err, climit - count), 1 << 12) >> 13), 1);
                     cm[iu] = v;
+                    if (spec_next && nrow_ok && iu - nrow < 32u) s_row[iu - nrow] = v;   // (an index masked back into the table may land in the next row)
                 }
             }
             c8 = (c8 << 1) | (u32)y;
             if (c8 >= 256u) { }
             else if (c8 >= 16u && c8 < 32u) hmap4 = ((hmap4 & 0xfu) << 5) | ((u32)y << 4) | 1u;
             else hmap4 = (hmap4 & 0x1f0u) | (((hmap4 & 0xfu) * 2u + (u32)y) & 0xfu);
+            spec = spec_next;
+            yprev = (u32)y;
 #ifdef ZPG_PROF
             {
                 const u64 t4 = __builtin_readcyclecounter();
@@ -1189,7 +1274,7 @@ __global__ void __launch_bounds__(1024) k_gdec(const DBatch B, const GCfg cfg)
         for (int i = tid; i < 256; i += nthr) d2[i] = B.dt2k[i];
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform, and known to the compiler as such: component constants in SGPRs, scalar branches)
     const int n = cfg.n;
     const int wg_slot0 = blockIdx.x * cfg.bpw;
     const int nslots = B.nslots;
@@ -1346,7 +1431,7 @@ extern "C" int zpq_gdec_applies(const DModel *M)
 static int gdec_wgs_per_cu(const zpqg::GCfg &cfg, size_t dlds)
 {
     const int wgs = (int)((160 * 1024) / dlds);
-    const int by_waves = 20 / (cfg.n + 1);                     // 83 VGPRs: five waves per SIMD
+    const int by_waves = 16 / (cfg.n + 1);                     // 98 VGPRs: four waves per SIMD
     const int w = wgs < by_waves ? wgs : by_waves;
     return w < 1 ? 1 : w;
 }
@@ -1364,14 +1449,11 @@ extern "C" int zpq_launch_gdec(const DBatch *B, const DModel *hostM, int nslots,
     zpqg::GCfg cfg;
     size_t lds = 0, dlds = 0;
     if (!gpipe_cfg(hostM, &cfg, &lds, &dlds)) return ZPQ_E_INTERNAL;
-    // The decoder is bound by the latency of a bit's trip to the tables, not by instruction issue: a batch that does not fill
-    // every workgroup slot of the chip with 64 blocks per workgroup is spread over more workgroups of 32 or 16 lanes.
-    static int cus = 0;
-    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus < 1) cus = 256; }
-    const char *ev = getenv("ZPQ_GDEC_BPW");                     // tuning / test knob
+    // 64 blocks per workgroup.  (Spreading a batch that leaves workgroup slots empty over more workgroups of 32 or 16 lanes
+    // was measured: C4b, 16 384 blocks: 2368 ms at 64 lanes, 3056 at 32, 4927 at 16 -- a bit costs a wave the same whatever
+    // its lanes; ZPQ_GDEC_BPW keeps the knob.)
+    const char *ev = getenv("ZPQ_GDEC_BPW");
     int bpw = zpqg::BPW;
-    const int want = cus * gdec_wgs_per_cu(cfg, dlds);
-    while (bpw > 16 && (nslots + bpw - 1) / bpw < want) bpw /= 2;
     if (ev && (atoi(ev) == 16 || atoi(ev) == 32 || atoi(ev) == 64)) bpw = atoi(ev);
     cfg.bpw = bpw;
     const int nwg = (nslots + bpw - 1) / bpw;
