@@ -856,9 +856,9 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
 
     u32 prev = 0, hctx = 0;
     i32 ma = (TYPE == ZT_MATCH) ? ca : 0, mb = (TYPE == ZT_MATCH) ? cb : 0, mc = 0, mlimit = 0;   // quirk Q17
-    u32 mpred = 0;
+    u32 mpred = 0, mcand = 0;
     u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0, roff = 0;
-    (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mpred; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
+    (void)ma; (void)mb; (void)mc; (void)mlimit; (void)mpred; (void)mcand; (void)r0; (void)r1; (void)r2; (void)r3; (void)roff;
     // Inside a nibble the NEXT bit's contexts are known now but for this bit: its table entries are asked for under both values
     // (CM, MIX2, MIX: neighbouring entries / rows; ICM, ISSE: the two states the nibble's row holds for them) while this bit
     // is still being predicted, and picked when the bit is known.  An entry that this bit's training then rewrites is taken from
@@ -924,7 +924,10 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
                         else { const uint2 w = *reinterpret_cast<const uint2 *>(cm + st * 2); nx0 = w.x; nx1 = w.y; }
                     }
                 } else if (TYPE == ZT_MATCH) {
-                    if (kb == 0 && ma != 0) mpred = ht[wsub(mlimit, mb) & (i32)(ht_len - 1)];
+                    if (kb == 0) {                               // the predicted byte, and the candidate position the byte's END will want
+                        mpred = ht[wsub(mlimit, mb) & (i32)(ht_len - 1)];
+                        mcand = cm[(i32)hctx & (i32)(cm_len - 1)];
+                    }
                 } else if (TYPE == ZT_MIX2) {
                     idx = (hctx + (c8 & (u32)cmask)) & (u32)(cc - 1);
                     if (!spec) nx0 = a16[idx];
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
             mlimit = wadd(mlimit, 1) & mask;
             const i32 cmi = (i32)hctx & (i32)(cm_len - 1);
             if (ma == 0) {
-                mb = wsub(mlimit, (i32)cm[cmi]);
+                mb = wsub(mlimit, (i32)mcand);
                 if ((mb & mask) != 0) {
                     while (ma < 255) {
                         u32 x[4], z[4];
@@ -1184,25 +1187,36 @@ __device__ __forceinline__ void coder_dec(const DStage &S)
     const bool pp = (B.flags & ZPQ_FLAG_PP) != 0;
     const u8 *const src = S.src;
     const u32 nin = S.nin;
-    // the coded stream: the aligned dword under the read position and the one after it, asked for four bytes early
-    u32 ipos = 0, w0 = 0, w1 = 0;
-    const uintptr_t s0 = reinterpret_cast<uintptr_t>(src);
+    // The coded stream: an eight-byte window over the read position (aligned dwords) and the dword behind it, asked for one bit
+    // step before it can be needed.  No load sits inside the divergent byte loop of the decoder (the compiler would wait for
+    // it at the loop's join): a step -- the first four bytes, an EOF flag, a bit -- takes at most four bytes out of the
+    // window, refill() then moves the window on by a dword if it can and asks for the next one, on every lane alike.
+    const uintptr_t s0 = reinterpret_cast<uintptr_t>(src), base = s0 & ~(uintptr_t)3;
     auto dword_at = [&](const uintptr_t a) -> u32 {              // a: aligned; 0 when the dword holds no byte of the stream
-        return (a < s0 + nin && a + 4 > s0) ? *reinterpret_cast<const u32 *>(a) : 0u;
+        const bool in = S.active && a < s0 + nin && a + 4 > s0;
+        const u32 v = *reinterpret_cast<const u32 *>(in ? a : reinterpret_cast<uintptr_t>(B.squash));
+        return in ? v : 0u;
     };
-    if (S.active && nin) { w0 = dword_at(s0 & ~(uintptr_t)3); w1 = dword_at((s0 & ~(uintptr_t)3) + 4); }
+    u64 win = (u64)dword_at(base) | ((u64)dword_at(base + 4) << 32);
+    u32 wpos = (u32)(s0 & 3), wn = dword_at(base + 8), ipos = 0;
+    uintptr_t naddr = base + 12;
     auto next_byte = [&]() -> u32 {
-        const uintptr_t a = s0 + ipos;
-        const u32 c = ipos < nin ? (w0 >> (8u * (u32)(a & 3))) & 255u : 0u;
-        if (ipos < nin) {
-            ipos++;
-            if (((a + 1) & 3) == 0) { w0 = w1; w1 = dword_at((a + 1) + 4); }
-        }
+        const u32 c = ipos < nin ? (u32)(win >> (8u * wpos)) & 255u : 0u;
+        const u32 adv = ipos < nin ? 1u : 0u;
+        ipos += adv; wpos += adv;
         return c;
+    };
+    auto refill = [&]() {
+        const bool need = wpos >= 4u;
+        win = need ? ((win >> 32) | ((u64)wn << 32)) : win;
+        wpos = need ? wpos - 4u : wpos;
+        wn = dword_at(need ? naddr : naddr - 4);                 // (not needed: the same dword again)
+        naddr += need ? 4 : 0;
     };
     u32 low = 1, high = 0xFFFFFFFFu, code = 0, opos = 0, first = 0xFFFFFFFFu;
     bool got_first = false, alive = S.active;
     if (alive) for (int k = 0; k < 4; k++) code = (code << 8) | next_byte();
+    refill();
     auto shift_in = [&]() {
         while ((high ^ low) < 0x1000000u) {
             low <<= 8; high = (high << 8) | 255u; low = low ? low : 1u;
@@ -1215,6 +1229,7 @@ __device__ __forceinline__ void coder_dec(const DStage &S)
             else low += 1;
             shift_in();
         }
+        refill();
         s_alive[S.lane] = alive ? 1u : 0u;
         const bool any = __any(alive ? 1 : 0) != 0;
         if (S.lane == 0) *s_any = any ? 1u : 0u;
@@ -1235,6 +1250,7 @@ __device__ __forceinline__ void coder_dec(const DStage &S)
                 shift_in();
             }
             s_y[S.lane] = y;
+            refill();
             c8 = (c8 << 1) | y;
             lds_barrier();
         }
