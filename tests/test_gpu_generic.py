@@ -192,7 +192,7 @@ def test_first_segment_takes_the_fast_kernel_and_state_is_materialised_on_demand
     the oracle's multi-segment coding in both directions, including a decoder that sees PP bytes != 0."""
     header = O.level_header(2) if name == "2" else C4B
     model = zpq.Model(header=header)
-    fast = "k_chain" if name == "2" else "k_rows"
+    fast = "k_chain" if name == "2" else "k_gdec"                 # (general models: a wave per component in both directions)
     fast_enc = fast if name == "2" else "k_gpipe"             # (one block: below k_pipe's minimum; general models: the wave pipeline)
     segs_in = [INPUTS["text2k"][:900], b"", INPUTS["lcg4k"][:700], INPUTS["text2k"][300:1300]]
     blk = zpq.Block(gpu_ctx, model)

@@ -34,6 +34,13 @@ def lib():
     p = lib_path()
     if not os.path.exists(p):
         raise ZpqError(-1, "libzpaq_hip.so is not built (run __graft_entry__.build() or make -C zpaq-v_amd/csrc)")
+    # PyTorch-ROCm ships its own HIP runtime; a process that maps this library (and with it the system's libamdhip64) BEFORE
+    # torch ends up with two runtimes and the second one to initialise sees no device (measured: build() then smoke() in one
+    # process).  Where torch is there -- it is on every box this harness runs on -- its runtime is mapped first, always.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001
+        pass
     L = C.CDLL(p)
     vp, u8p, u32, i32, u64 = C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.c_uint64
     L.zpq_level_header.argtypes = [i32, vp, i32, vp, vp, vp, vp]
