@@ -784,6 +784,9 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
 // component's prediction, decodes the bit and hands it back; every wave trains its component and moves to the next bit's
 // contexts.  Against zpq_lanes.hip (lane = component, four blocks per wave) a wave issues only its own type's code, for
 // 64 blocks, and the bit costs one trip to the tables plus the chain of levels.
+#ifndef ZPG_SSE_SPEC
+#define ZPG_SSE_SPEC 1                               // an SSE asks for the next bit's two candidate rows (timing builds: 0)
+#endif
 constexpr int D_P = L_DT2K + 512;                // i32 p[16][BPW]: this bit's predictions
 constexpr int D_Y = D_P + 16 * BPW * 4;          // u32 y[BPW]
 constexpr int D_ALIVE = D_Y + BPW * 4;           // u32 alive[BPW]: the block has not met its EOF flag yet
@@ -863,7 +866,7 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
     // (CM, MIX2, MIX: neighbouring entries / rows; ICM, ISSE: the two states the nibble's row holds for them) while this bit
     // is still being predicted, and picked when the bit is known.  An entry that this bit's training then rewrites is taken from
     // the training (tr_*), not from the load that went out before it.
-    constexpr bool SPEC = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX || TYPE == ZT_SSE;
+    constexpr bool SPEC = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX || (TYPE == ZT_SSE && ZPG_SSE_SPEC);
     constexpr bool FWD = SPEC && TYPE != ZT_SSE;                 // (an SSE trains its CURRENT row; the next bit's row is patched in LDS if ever hit)
     bool spec = false;
     u32 sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0, tr_a = 0xFFFFFFFFu, tr0 = 0, tr1 = 0, yprev = 0;
