@@ -109,6 +109,13 @@ def test_all_nine_types_ragged_batch_slot_reuse_and_overflow(zpq, gpu_ctx):
         assert (both_decoders(zpq, gpu_ctx, model, want, blocks, zpq.FLAG_PP, 7016) == 0).all() and gpu_ctx.last_slots == 70
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
+    # a batch of nothing but empty blocks (no input byte to read; with the PP flag one coded byte, without it none)
+    for flags in (zpq.FLAG_PP, 0):
+        empty = [b""] * 5
+        coded, status, _ = gpu_ctx.encode_blocks(model, empty, flags=flags)
+        assert gpu_ctx.last_kernel_name == "k_gpipe<encode>" and (status == 0).all()
+        assert coded == [O.Codec(C4B).encode(b"", pp=bool(flags)) for _ in empty]
+        assert (both_decoders(zpq, gpu_ctx, model, coded, empty, flags, 16) == 0).all()
     small = [INPUTS["lcg4k"], b"abc", INPUTS["text2k"]]
     _, status, out_len = gpu_ctx.encode_blocks(model, small, cap=64)
     assert gpu_ctx.last_kernel_name == "k_gpipe<encode>"
