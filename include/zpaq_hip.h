@@ -88,7 +88,10 @@ int zpq_ctx_last_slots(const zpq_ctx *);
 unsigned zpq_ctx_last_line_store(const zpq_ctx *);
 /* How many blocks of this model a single launch keeps resident on this ctx (the smaller of what
  * the CUs' LDS/wave slots hold and what the state budget holds); a larger batch is worked off by
- * the resident groups in turn.  flags as for the batch calls (kernel choice).  < 0 = ZPQ_E_*. */
+ * the resident groups in turn.  Where the encoder and the decoder of a model hold different numbers
+ * (general models: a wave per component either way, different register budgets) the smaller one is
+ * reported: a batch of this size is one round in both directions.  flags as for the batch calls
+ * (kernel choice).  < 0 = ZPQ_E_*. */
 int zpq_ctx_resident_capacity(zpq_ctx *, const zpq_model *, uint32_t flags);
 /* Time of the last batch's coding kernel alone, from HIP events on the ctx stream (ms). */
 float zpq_ctx_last_kernel_ms(const zpq_ctx *);
