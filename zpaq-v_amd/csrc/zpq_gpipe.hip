@@ -784,6 +784,10 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
 // component's prediction, decodes the bit and hands it back; every wave trains its component and moves to the next bit's
 // contexts.  Against zpq_lanes.hip (lane = component, four blocks per wave) a wave issues only its own type's code, for
 // 64 blocks, and the bit costs one trip to the tables plus the chain of levels.
+#ifndef ZPG_HASH_SPEC
+#define ZPG_HASH_SPEC 0                              // ICM / ISSE asking for the two states the next bit can meet: two random lines of the
+                                                     // state table where one is needed -- measured 2081 ms against 2038 without (same box); 1: timing builds
+#endif
 #ifndef ZPG_SSE_SPEC
 #define ZPG_SSE_SPEC 1                               // an SSE asks for the next bit's two candidate rows (timing builds: 0)
 #endif
@@ -866,8 +870,9 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
     // (CM, MIX2, MIX: neighbouring entries / rows; ICM, ISSE: the two states the nibble's row holds for them) while this bit
     // is still being predicted, and picked when the bit is known.  An entry that this bit's training then rewrites is taken from
     // the training (tr_*), not from the load that went out before it.
-    constexpr bool SPEC = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX || (TYPE == ZT_SSE && ZPG_SSE_SPEC);
-    constexpr bool FWD = SPEC && TYPE != ZT_SSE;                 // (an SSE trains its CURRENT row; the next bit's row is patched in LDS if ever hit)
+    constexpr bool SPEC = TYPE == ZT_CM || ((TYPE == ZT_ICM || TYPE == ZT_ISSE) && ZPG_HASH_SPEC) || TYPE == ZT_MIX2 || TYPE == ZT_MIX || (TYPE == ZT_SSE && ZPG_SSE_SPEC);
+    // the entry arrives in nx0 / nx1 / nxw whether asked for early or not, and is taken from there -- or from the last training
+    constexpr bool FWD = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX;   // (an SSE trains its CURRENT row; the next bit's row is patched in LDS if ever hit)
     bool spec = false;
     u32 sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0, tr_a = 0xFFFFFFFFu, tr0 = 0, tr1 = 0, yprev = 0;
     u32 nx0 = 0, nx1 = 0;                                        // ... picked as soon as the bit is known, BEFORE this bit's stores go out:
