@@ -788,6 +788,20 @@ __global__ void __launch_bounds__(1024) k_gpipe(const DBatch B, const GCfg cfg)
 #define ZPG_HASH_SPEC 0                              // ICM / ISSE asking for the two states the next bit can meet: two random lines of the
                                                      // state table where one is needed -- measured 2081 ms against 2038 without (same box); 1: timing builds
 #endif
+// Which component types ask for the next bit's entries under both values of the bit -- decided by A/B on one box (C4b, 16 384
+// blocks, decode ms; default 2079-2083): the kernel runs at ~0.85 of the chip's random-line rate, so a request pays only where it
+// brings no new line (CM, MIX2: the neighbour word: 2090 / 2094 without) or takes a whole trip off the end of the prediction
+// chain (SSE, the last level: 2330 without); the MIX's two rows (2001 WITHOUT) and the two states of an ICM / ISSE (2038
+// without) cost more in lines than they hide.
+#ifndef ZPG_CM_SPEC
+#define ZPG_CM_SPEC 1
+#endif
+#ifndef ZPG_MIX2_SPEC
+#define ZPG_MIX2_SPEC 1
+#endif
+#ifndef ZPG_MIX_SPEC
+#define ZPG_MIX_SPEC 0
+#endif
 #ifndef ZPG_SSE_SPEC
 #define ZPG_SSE_SPEC 1                               // an SSE asks for the next bit's two candidate rows (timing builds: 0)
 #endif
@@ -870,7 +884,8 @@ __device__ __forceinline__ void comp_dec(const DStage &S)
     // (CM, MIX2, MIX: neighbouring entries / rows; ICM, ISSE: the two states the nibble's row holds for them) while this bit
     // is still being predicted, and picked when the bit is known.  An entry that this bit's training then rewrites is taken from
     // the training (tr_*), not from the load that went out before it.
-    constexpr bool SPEC = TYPE == ZT_CM || ((TYPE == ZT_ICM || TYPE == ZT_ISSE) && ZPG_HASH_SPEC) || TYPE == ZT_MIX2 || TYPE == ZT_MIX || (TYPE == ZT_SSE && ZPG_SSE_SPEC);
+    constexpr bool SPEC = (TYPE == ZT_CM && ZPG_CM_SPEC) || ((TYPE == ZT_ICM || TYPE == ZT_ISSE) && ZPG_HASH_SPEC) || (TYPE == ZT_MIX2 && ZPG_MIX2_SPEC) ||
+                          (TYPE == ZT_MIX && ZPG_MIX_SPEC) || (TYPE == ZT_SSE && ZPG_SSE_SPEC);
     // the entry arrives in nx0 / nx1 / nxw whether asked for early or not, and is taken from there -- or from the last training
     constexpr bool FWD = TYPE == ZT_CM || TYPE == ZT_ICM || TYPE == ZT_ISSE || TYPE == ZT_MIX2 || TYPE == ZT_MIX;   // (an SSE trains its CURRENT row; the next bit's row is patched in LDS if ever hit)
     bool spec = false;
