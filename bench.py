@@ -226,19 +226,26 @@ def measured_traffic(dom_name, nb):
     """HBM bytes per launch of the dominant kernel from the round's rocprofv3 --pmc passes
     (profiles/r03_pmc.json, written by tools/pmc_collect.py).  Only reported when that profile was
     taken on exactly the kernel source this run executes; otherwise null, with the reason."""
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
-    if not os.path.exists(pmc):
-        return None, "no PMC profile for this round yet"
-    try:
-        pj = json.load(open(pmc))
-        if pj.get("_kernel_src_sha") != kernel_src_sha():
-            return None, "profiles/r03_pmc.json was taken on another kernel source (%s)" % pj.get("_kernel_src_sha")
-        t = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
-        if t is None:
-            return None, "kernel not in profile"
-        return int(t * nb / pj.get("_blocks_per_launch", nb)), "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes, %s" % pj.get("_note", "")
-    except Exception as e:                                      # noqa: BLE001
-        return None, "profile unreadable: %r" % (e,)
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")), reverse=True)   # newest round first
+    if not cands:
+        return None, "no PMC profile in profiles/"
+    why = []
+    for pmc in cands:
+        name = os.path.relpath(pmc, ROOT)
+        try:
+            pj = json.load(open(pmc))
+            if pj.get("_kernel_src_sha") != kernel_src_sha():
+                why.append("%s was taken on another kernel source (%s)" % (name, pj.get("_kernel_src_sha")))
+                continue
+            t = pj.get(dom_name, {}).get("hbm_bytes_per_launch")
+            if t is None:
+                why.append("%s: kernel not in profile" % name)
+                continue
+            return int(t * nb / pj.get("_blocks_per_launch", nb)), "%s: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes, %s" % (name, pj.get("_note", ""))
+        except Exception as e:                                      # noqa: BLE001
+            why.append("%s unreadable: %r" % (name, e))
+    return None, "; ".join(why[:2])
 
 
 def main():
@@ -253,7 +260,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip per_class / value_incl_pcie / secondary (N=1 extras)")
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=32)
     ap.add_argument("--cpu-one-thread-blocks", type=int, default=48)
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal)")
+    ap.add_argument("--backend", default="gloo",
+                    help="process group for the barrier and the two scalar reductions of an N > 1 run: gloo (default: CPU tensors; the "
+                         "data path has no collective and the north star says no RCCL -- this is also the path the rehearsals ran) or nccl (= RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--state-budget-gib", type=float, default=0.0, help="cap the per-ctx state pool (rehearsals sharing one GPU)")
@@ -395,6 +404,9 @@ def main():
                                        " (C5's per-GPU share of 65536 blocks over 8 GPUs)" if nb == 8192 else ""),
                        "blocks_per_gpu": nb, "block_bytes": size, "level": a.level,
                        "parallelism": "block b -> gpu b mod %d, no collective" % world},
+            "value_definition": "device-resident: inputs and outputs in HBM when the timed region starts and ends; value_incl_pcie "
+                                "(N = 1) is SURVEY 8(d)'s t, with H2D/D2H inside the calls",
+            "backend": a.backend if world > 1 else None,
             "roundtrip_bit_exact": all_ok, "ratio": round(ratio, 4),
             "coded_bytes": int(stats[0].item()),
             "comp_MBps": round(nb * size / (enc_ms * 1e-3) / 1e6, 1),
@@ -499,7 +511,7 @@ def main():
             run_cfg("C4a_level5", "level 5 as shipped (%s, levels.v:294-335), 64 KiB blocks at resident capacity" % LEVEL_NAMES[5],
                     z.Model(level=5), 0, ALG_BYTES_PER_INPUT_BYTE_L[5], 1.125, None, pcie=True)
             run_cfg("C4b_all_nine_types", "synthetic header with all nine component types (SURVEY 8(d) C4b), 64 KiB blocks at resident "
-                                          "capacity (encode: a wave per component, lane = block; decode: four blocks per wave)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
+                                          "capacity (encode k_gpipe: a wave per component, lane = block, a pipeline over bytes; decode k_gdec: the same waves, bit-synchronous)", z.Model(header=C4B), 0, ALG_BYTES_C4B, 6.0, None)
             res["secondary"] = secondary
 
         for _name, _fn in (("per_class", _per_class), ("incl_pcie", _incl_pcie), ("secondary", _secondary)):

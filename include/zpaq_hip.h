@@ -38,7 +38,8 @@ extern "C" {
 #define ZPQ_E_NOMEM (-6)     /* host or device allocation failed */
 #define ZPQ_E_OVERFLOW (-7)  /* per block: output slab too small (out_len holds the needed size if known) */
 #define ZPQ_E_VMSTEPS (-8)   /* per block: HCOMP exceeded ZPQ_VM_STEP_CAP steps in one run (reference would hang) */
-#define ZPQ_E_INTERNAL (-9)
+#define ZPQ_E_INTERNAL (-9)  /* self-check failed, or a C++ exception (host allocation, the HIP runtime) was stopped at this boundary */
+#define ZPQ_E_CLOSED (-10)   /* the zpq_ctx this handle (a ctx pointer, a zpq_block) belongs to has been destroyed */
 
 #define ZPQ_VM_STEP_CAP (1u << 20)
 
@@ -67,6 +68,12 @@ uint64_t zpq_model_state_bytes(const zpq_model *); /* device bytes of one block'
 int zpq_model_has_fast_path(const zpq_model *);    /* 1 if the LDS-resident chain kernel applies */
 
 /* ---- per-device context: stream, read-only tables, per-block state slots ---- */
+/* Handle lifetime: handles may be destroyed in ANY order (a garbage-collected host language will).  zpq_ctx_destroy
+ * releases the device state of every zpq_block still alive on the ctx and orphans it: later calls on such a block
+ * return ZPQ_E_CLOSED, zpq_block_destroy still has to be called and frees the host struct only.  A zpq_block keeps
+ * its zpq_model alive (zpq_model_destroy drops the creator's reference).  Calls on a destroyed zpq_ctx* return
+ * ZPQ_E_CLOSED / ZPQ_E_ARG (the pointer is checked against the set of living contexts), zpq_ctx_destroy twice is a
+ * no-op.  What stays the caller's duty: no call may be RUNNING on a ctx while another thread destroys it. */
 typedef struct zpq_ctx zpq_ctx;
 int zpq_ctx_create(int device, zpq_ctx **out);
 void zpq_ctx_destroy(zpq_ctx *);
@@ -210,6 +217,8 @@ int zpq_block_decode_segment(zpq_block *, const uint8_t *in, size_t n, uint32_t 
 /* ---- inspection / test hooks ---- */
 /* squash_table / stretch_table as built at start-up (predictor.v:11-15,21-96). */
 int zpq_tables(int32_t *squash4096, int32_t *stretch32768);
+/* dt_table (predictor.v:111-166), dt2k (predictor.v:99-106), StateTable.ns (statetable.v:15-57); any pointer may be NULL. */
+int zpq_tables_ex(int32_t *dt1024, int32_t *dt2k256, uint8_t *ns1024);
 /* Run the device ZPAQL VM over `in` on a fresh block and return, for every input
  * byte, the n context hashes Predictor.update copies out (predictor.v:809-816):
  * h_out[i*ncomp + k].  Exercises zpaql.v:167-954 alone. */

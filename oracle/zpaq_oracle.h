@@ -9,7 +9,10 @@
  *
  * Parity status: the reference is V source and no V compiler exists in this
  * environment, so the oracle cannot be run against a reference binary.  It is
- * pinned by (1) every known-answer test the reference's own zpaq_test.v holds
+ * pinned by (0) the reference's own literal data on this path -- state_table_data,
+ * dt_table, the six level headers, compsize, the block locator -- read from the V
+ * source into tests/golden/reference_literals.json and compared entry by entry
+ * (tests/test_reference_literals.py), (1) every known-answer test the reference's own zpaq_test.v holds
  * for this path (StateTable/cminit/oplen/squash/stretch ranges/coder initial
  * state/level-0 header/level-1 "Hello World!" round trip) and (2) byte-for-byte
  * agreement with a second, independently written Python restatement

@@ -46,7 +46,8 @@ def test_chain_matches_golden_streams(zpq, gpu_ctx, level):
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         flags = zpq.FLAG_PP if mode == "pp" else 0
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=flags)
-        assert gpu_ctx.last_kernel_name == ("k_pipe<encode>" if len(blocks) >= 12 else "k_chain<encode>")
+        pipe = "k_pipe2<encode>" if level == 1 else "k_pipe<encode>"     # (level 1, dense: every stage split into two waves)
+        assert gpu_ctx.last_kernel_name == (pipe if len(blocks) >= 12 else "k_chain<encode>")
         assert (status == 0).all()
         for k, c in zip(ks, coded):
             assert hashlib.sha256(c).hexdigest() == G["streams"][k]["sha256"], k
@@ -140,7 +141,7 @@ def test_chain_full_size_batch_properties(zpq, gpu_ctx):
     """BASELINE size (level 2, 8192 x 64 KiB, buffers resident in HBM): size-independent
     properties -- encode -> decode is the identity on every block, every status is OK, the
     decoder consumed exactly the bytes the encoder produced -- plus byte parity with the
-    CPU oracle on a random sample of blocks and a checksum of checksums over all coded
+    CPU oracle on EVERY block and a checksum of checksums over all coded
     streams that must not depend on how blocks were grouped into launches."""
     import torch
     nb, size = 8192, 65536
@@ -171,11 +172,14 @@ def test_chain_full_size_batch_properties(zpq, gpu_ctx):
     assert bool((d_code == -1).all())                    # Decoder.code after EOF = the 4 flush bytes FF FF FF FF
     lens = d_len.cpu().numpy()
     out = d_out.cpu().numpy()
-    rnd = random.Random(2024)
-    sample = sorted(rnd.sample(range(nb), 24))
-    want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=8, slack=cap)
-    for i, w in zip(sample, want):
-        assert out[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+    # EVERY coded stream of the headline batch against the oracle (a 24-block sample covered 0.3 %):
+    # the oracle codes 8192 x 64 KiB in about 8 s on the box's 16 host threads, in chunks that keep its slabs small
+    nthreads = min(16, os.cpu_count() or 1)
+    for c0 in range(0, nb, 1024):
+        idx = range(c0, min(nb, c0 + 1024))
+        want = O.encode_blocks(model.header, [arr[i].tobytes() for i in idx], nthreads=nthreads, slack=cap)
+        for i, w in zip(idx, want):
+            assert int(lens[i]) == len(w) and out[i * cap:i * cap + len(w)].tobytes() == w, i
     # checksum of checksums: same 512 blocks coded in a separate, smaller launch
     sub = list(range(0, nb, 16))
     coded_sub, status, _ = gpu_ctx.encode_blocks(model, [arr[i].tobytes() for i in sub], cap=cap)

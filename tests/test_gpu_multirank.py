@@ -59,11 +59,13 @@ def test_plain_invocation_starts_its_own_ranks(gpu_ctx):
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "512"] + common,
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
-    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+    # no --backend: the DEFAULT process group (gloo: CPU tensors for the barrier and the two reductions) is what the driver's
+    # N > 1 command line gets, so this is the path a SCALE run takes ("what's weak" 9)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device",
                           "--blocks", "256"] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     r1, r2 = _json_line(one.stdout), _json_line(two.stdout)
-    assert r2["n_gpus"] == 2 and len(r2["devices"]) == 2
+    assert r2["n_gpus"] == 2 and len(r2["devices"]) == 2 and r2["backend"] == "gloo"
     assert sorted(d["rank"] for d in r2["devices"]) == [0, 1]
     assert len({d["pid"] for d in r2["devices"]}) == 2           # two processes really ran
     assert r2["roundtrip_bit_exact"] and r1["coded_bytes"] == r2["coded_bytes"] > 0

@@ -25,7 +25,7 @@ def encode_both(zpq, gpu_ctx, monkeypatch, model, blocks, flags=None, cap=None):
     monkeypatch.delenv("ZPQ_ENC_PIPE", raising=False)
     assert len(blocks) >= 12                     # (smaller batches stay with the lane-per-component encoder)
     a, sa, la = gpu_ctx.encode_blocks(model, blocks, **kw)
-    assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
+    assert gpu_ctx.last_kernel_name in ("k_pipe<encode>", "k_pipe2<encode>")
     monkeypatch.setenv("ZPQ_ENC_PIPE", "0")
     b, sb, lb = gpu_ctx.encode_blocks(model, blocks, **kw)
     assert gpu_ctx.last_kernel_name == "k_chain<encode>"
@@ -94,7 +94,7 @@ def test_rounds_and_partial_workgroups(zpq, gpu_ctx, monkeypatch, level):
     zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, nslots * model.state_bytes + 1000)
     try:
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
-        assert gpu_ctx.last_kernel_name == "k_pipe<encode>" and gpu_ctx.last_slots == nslots
+        assert gpu_ctx.last_kernel_name == ("k_pipe2<encode>" if level == 1 else "k_pipe<encode>") and gpu_ctx.last_slots == nslots
         assert (status == 0).all() and coded == want
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
@@ -163,7 +163,7 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
     gpu_ctx.encode_blocks_dev(model, nb, d_in.data_ptr(), in_off.data_ptr(), zpq.FLAG_PP, d_out.data_ptr(),
                               out_off.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
     gpu_ctx.sync()
-    assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
+    assert gpu_ctx.last_kernel_name in ("k_pipe<encode>", "k_pipe2<encode>")
     if level >= 3 and nb >= 3072:
         # what bench.py measures: every block resident at once, hash tables in the compact line store
         # (resident blocks = what the LDS holds, 4096 / 3072, unless this process's other buffers leave less HBM)
@@ -203,3 +203,32 @@ def test_blocks_larger_than_64k(zpq, gpu_ctx, monkeypatch, level):
     assert coded == O.encode_blocks(model.header, blocks, nthreads=8)
     dec, status, *_ = gpu_ctx.decode_blocks(model, coded, cap=400100)
     assert (status == 0).all() and dec == blocks
+
+
+def test_split_stage_encoder_orders_and_rejected_orders(zpq, gpu_ctx, monkeypatch):
+    """Level 1 runs k_pipe2 (every stage split into a history and a weights wave) by default; ZPQ_ENC_SPLIT=0 puts it back on
+    k_pipe; another complete wave order is taken; an order that names a component the model does not have, leaves out the
+    coder, or names a stage twice is IGNORED (it used to be launched as given).  Same coded bytes every time."""
+    rnd = random.Random(4711)
+    for level, orders in ((1, (None, "0", "60231", "6823", "6019", "02316", "6089", "64523", "0123", "60011", "602316")),
+                          (2, (None, "0", "6024135", "689a", "682345", "60231", "6024137", "6802345"))):
+        model = zpq.Model(level=level)
+        blocks = mixed_blocks(rnd, 40, [0, 1, 300, 1200, 2048])
+        want = O.encode_blocks(model.header, blocks, nthreads=4)
+        default = "k_pipe2<encode>" if level == 1 else "k_pipe<encode>"
+        for order in orders:
+            if order is None:
+                monkeypatch.delenv("ZPQ_ENC_SPLIT", raising=False)
+            else:
+                monkeypatch.setenv("ZPQ_ENC_SPLIT", order)
+            coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
+            name = gpu_ctx.last_kernel_name
+            assert (status == 0).all() and coded == want, (level, order, name)
+            valid = {1: ("60231", "6823", "6019", "02316"), 2: ("6024135", "689a", "682345")}[level]
+            if order == "0":
+                assert name == "k_pipe<encode>", (level, order, name)
+            elif order in valid:
+                assert name == "k_pipe2<encode>", (level, order, name)
+            else:
+                assert name == default, (level, order, name)      # None, or a rejected order: the default encoder
+    monkeypatch.delenv("ZPQ_ENC_SPLIT", raising=False)

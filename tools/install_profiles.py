@@ -25,7 +25,7 @@ shutil.copy(os.path.join(prof, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "
 for i in range(1, 5):
     f = os.path.join(prof, "pmc%d" % i, "pmc%d_counter_collection.csv" % i)
     rows = list(csv.DictReader(open(f)))
-    keep = [r for r in rows if "k_chain" in r["Kernel_Name"] or "k_pipe" in r["Kernel_Name"]]
+    keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_chain", "k_pipe", "k_dpipe", "k_gpipe", "k_gdec", "k_rows", "k_lanes", "k_generic", "k_sha1", "k_gather"))]
     w = csv.DictWriter(open(os.path.join(dst, "%s_pmc_pass%d.csv" % (rnd, i)), "w", newline=""), fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(keep)

@@ -4,8 +4,10 @@ This is plumbing only: every compute call goes to the HIP library.  There is no
 Python or CPU fallback -- if the shared library is missing, or no GPU is
 present, the calls raise ZpqError.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -14,6 +16,29 @@ FLAG_PP = 1
 FLAG_GENERIC = 2
 FLAG_LANES = 8
 _LIB = None
+# Handle lifetime on the Python side (the C side tolerates any destroy order as well, include/zpaq_hip.h): every live
+# Context, Block and PinnedArray is tracked; Context.close() closes its blocks first; at interpreter exit everything
+# still alive is closed in that order by ONE atexit hook (registered when the library is loaded, i.e. after torch's own
+# hooks, so it runs before them and before any runtime is torn down) and from then on __del__ does nothing: a
+# destructor that runs during interpreter finalisation must not call into HIP any more.
+_LIVE_CTX = weakref.WeakSet()
+_LIVE_PINNED = weakref.WeakSet()
+_FINALIZING = False
+
+
+def _shutdown():
+    global _FINALIZING
+    for ctx in list(_LIVE_CTX):
+        try:
+            ctx.close()
+        except Exception:  # noqa: BLE001
+            pass
+    for arr in list(_LIVE_PINNED):
+        try:
+            arr.free()
+        except Exception:  # noqa: BLE001
+            pass
+    _FINALIZING = True
 
 
 class ZpqError(RuntimeError):
@@ -88,12 +113,14 @@ def lib():
     L.zpq_block_encode_segment.argtypes = [vp, u8p, C.c_size_t, u32, vp, C.c_size_t, vp]
     L.zpq_block_decode_segment.argtypes = [vp, u8p, C.c_size_t, u32, vp, C.c_size_t, vp, vp, vp, vp]
     L.zpq_tables.argtypes = [vp, vp]
+    L.zpq_tables_ex.argtypes = [vp, vp, vp]
     L.zpq_debug_contexts.argtypes = [vp, vp, u8p, C.c_size_t, vp]
     L.zpq_debug_encode_trace.argtypes = [vp, vp, u8p, C.c_size_t, u32, vp, C.c_size_t, vp, vp, C.c_size_t]
     L.zpq_status_string.argtypes = [i32]
     L.zpq_status_string.restype = C.c_char_p
     L.zpq_version.restype = C.c_char_p
     _LIB = L
+    atexit.register(_shutdown)
     return L
 
 
@@ -107,6 +134,15 @@ def status_string(code):
 def _ck(rc, what):
     if rc != 0:
         raise ZpqError(rc, what)
+
+
+def tables_ex():
+    """dt[1024], dt2k[256], ns[1024] as the library builds them (zpq_tables_ex)."""
+    dt = np.zeros(1024, dtype=np.int32)
+    dt2k = np.zeros(256, dtype=np.int32)
+    ns = np.zeros(1024, dtype=np.uint8)
+    _ck(lib().zpq_tables_ex(dt.ctypes.data, dt2k.ctypes.data, ns.ctypes.data), "zpq_tables_ex")
+    return dt, dt2k, ns
 
 
 def level_header(level):
@@ -134,10 +170,14 @@ class Model:
         _ck(lib().zpq_model_create(self.header, len(self.header), *self.offsets, C.byref(self.h)),
             "zpq_model_create")
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "h", None) and _LIB is not None:
-            _LIB.zpq_model_destroy(self.h)
+            _LIB.zpq_model_destroy(self.h)                 # (a Block built on the model keeps it alive: it is refcounted)
             self.h = None
+
+    def __del__(self):
+        if not _FINALIZING:
+            self.close()
 
     @property
     def ncomp(self):
@@ -162,6 +202,7 @@ class PinnedArray:
         if not self.ptr:
             raise ZpqError(-6, "zpq_host_alloc")
         self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+        _LIVE_PINNED.add(self)
 
     def free(self):
         if getattr(self, "ptr", None) and _LIB is not None:
@@ -169,7 +210,9 @@ class PinnedArray:
             _LIB.zpq_host_free(self.ptr)
             self.ptr = None
 
-    __del__ = free
+    def __del__(self):
+        if not _FINALIZING:
+            self.free()
 
 
 def _offsets(lengths):
@@ -185,14 +228,24 @@ class Context:
 
     def __init__(self, device=0):
         self.h = C.c_void_p()
+        self._children = weakref.WeakSet()                 # Blocks (and front-end handles) living on this ctx
         _ck(lib().zpq_ctx_create(device, C.byref(self.h)), "zpq_ctx_create")
+        _LIVE_CTX.add(self)
 
     def close(self):
+        """Destroy the ctx; whatever still lives on it is closed first."""
+        for child in list(getattr(self, "_children", ())):
+            try:
+                child.close()
+            except Exception:  # noqa: BLE001
+                pass
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.zpq_ctx_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if not _FINALIZING:
+            self.close()
 
     def sync(self):
         _ck(lib().zpq_ctx_sync(self.h), "zpq_ctx_sync")
@@ -309,13 +362,16 @@ class Block:
         self.ctx, self.model = ctx, model
         self.h = C.c_void_p()
         _ck(lib().zpq_block_create(ctx.h, model.h, C.byref(self.h)), "zpq_block_create")
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.zpq_block_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        if not _FINALIZING:
+            self.close()
 
     def encode_segment(self, data, flags=FLAG_PP, cap=None):
         cap = cap if cap is not None else len(data) * 17 + 4096

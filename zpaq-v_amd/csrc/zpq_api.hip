@@ -17,9 +17,12 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
+#include <exception>
 #include <map>
 #include <mutex>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/zpaq_hip.h"
@@ -134,11 +137,41 @@ struct zpq_ctx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     uint32_t *h_gate = nullptr;            // pinned, device-visible: "the rest of the striped upload has arrived"
     std::mutex mu;
+    std::vector<zpq_block *> children;     // blocks created on this ctx and not yet destroyed (guarded by g_reg_mu)
 };
 
+// ------------------------------------------------------------------ handle lifetime
+// A front end may drop its handles in any order (a garbage-collected host language does): a zpq_block may outlive its
+// zpq_ctx and its zpq_model.  The ctx keeps the list of its blocks and, when destroyed, releases their device state and
+// ORPHANS them (b->ctx = nullptr: every later call on the block returns ZPQ_E_CLOSED, zpq_block_destroy only frees the
+// host struct); a block holds a reference on its model.  A zpq_ctx* is checked against the set of living contexts at
+// every entry point, so that a call on a destroyed ctx is an error code, not a read of freed memory.
+static std::mutex g_reg_mu;
+static std::unordered_set<const zpq_ctx *> &live_set()
+{
+    static std::unordered_set<const zpq_ctx *> *s = new std::unordered_set<const zpq_ctx *>();   // never destroyed: handles may be dropped from atexit handlers
+    return *s;
+}
+static bool ctx_live(const zpq_ctx *c)
+{
+    if (!c) return false;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return live_set().count(c) != 0;
+}
+
+void zpq_note_exception(const char *where) noexcept
+{
+    try {
+        try { throw; }
+        catch (const std::exception &e) { fprintf(stderr, "[zpaq_hip] %s: C++ exception stopped at the C boundary: %s\n", where, e.what()); }
+        catch (...) { fprintf(stderr, "[zpaq_hip] %s: unknown C++ exception stopped at the C boundary\n", where); }
+    } catch (...) {
+    }
+}
+
 struct zpq_block {
-    zpq_ctx *ctx;
-    const zpq_model *model;
+    zpq_ctx *ctx;              // nullptr once the ctx has been destroyed (orphaned block)
+    const zpq_model *model;    // the block holds a reference (zpq_model_retain)
     uint8_t *slot;
     bool fresh;
     // A block's FIRST segment runs on the fast batch kernels (their state lives in LDS / the shared pool and is
@@ -152,7 +185,8 @@ struct zpq_block {
 
 // ------------------------------------------------------------------ ctx
 static int ctx_init(zpq_ctx *c, const zpq::Tables &T);
-extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
+static int set_max_block_bytes(zpq_ctx *c, uint64_t bytes);
+extern "C" int zpq_ctx_create(int device, zpq_ctx **out) try
 {
     if (!out) return ZPQ_E_ARG;
     *out = nullptr;
@@ -167,10 +201,11 @@ extern "C" int zpq_ctx_create(int device, zpq_ctx **out)
     if (!c) return ZPQ_E_NOMEM;
     c->device = device;
     const int rc = ctx_init(c, T);
+    { std::lock_guard<std::mutex> lk(g_reg_mu); live_set().insert(c); }
     if (rc != ZPQ_OK) { zpq_ctx_destroy(c); return rc; }   // releases whatever the failed step left behind
     *out = c;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
 {
@@ -214,15 +249,28 @@ static int ctx_init(zpq_ctx *c, const zpq::Tables &T)
         const int pct = ev ? atoi(ev) : 0;
         if (pct >= 101 && pct <= 400) c->sparse_pct = (uint32_t)pct;
     }
-    zpq_ctx_set_max_block_bytes(c, 65536);
+    set_max_block_bytes(c, 65536);
     return ZPQ_OK;
 }
 
-extern "C" void zpq_ctx_destroy(zpq_ctx *c)
+extern "C" void zpq_ctx_destroy(zpq_ctx *c) try
 {
-    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (!c || !live_set().erase(c)) return;            // null, destroyed already, or never a ctx of this library
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    {
+        // blocks that outlive their ctx: their device state goes with it, the host structs stay for zpq_block_destroy
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (zpq_block *b : c->children) {
+            if (b->slot) (void)hipFree(b->slot);
+            b->slot = nullptr;
+            b->ctx = nullptr;
+        }
+        c->children.clear();
+    }
     for (auto &kv : c->models) { (void)hipFree(kv.second.d_model); (void)hipFree(kv.second.d_img); }
     c->slots.release();
     c->s_in.release(); c->s_out.release(); c->s_inoff.release(); c->s_outoff.release();
@@ -245,25 +293,29 @@ extern "C" void zpq_ctx_destroy(zpq_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-}
+} ZPQ_CATCH(return)
 
-extern "C" int zpq_ctx_sync(zpq_ctx *c)
+extern "C" int zpq_ctx_sync(zpq_ctx *c) try
 {
-    if (!c) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return ZPQ_E_ARG;
     HIPCK(hipStreamSynchronize(c->stream));
     return ZPQ_OK;
-}
-extern "C" int zpq_ctx_device(const zpq_ctx *c) { return c ? c->device : -1; }
-extern "C" void *zpq_ctx_stream(zpq_ctx *c) { return c ? (void *)c->stream : nullptr; }
-extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes)
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
+extern "C" int zpq_ctx_device(const zpq_ctx *c) { return ctx_live(c) ? c->device : -1; }
+extern "C" void *zpq_ctx_stream(zpq_ctx *c) { return ctx_live(c) ? (void *)c->stream : nullptr; }
+extern "C" int zpq_ctx_set_state_budget(zpq_ctx *c, uint64_t bytes) try
 {
-    if (!c) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return ZPQ_E_ARG;
     c->budget = bytes;
     return ZPQ_OK;
-}
-extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
+extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes) try
 {
-    if (!c) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return ZPQ_E_ARG;
+    return set_max_block_bytes(c, bytes);
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
+static int set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
+{
     // A block of N bytes (+ PP byte) probes each hash table 2(N+1) times (predictor.v:558-560: once per nibble),
     // so it touches at most that many 64-byte lines.  The store holds sparse_pct % of that bound: probing is
     // linear over 4-slot groups, a worst-case block (every probe a new line) ends at 89 % load.
@@ -274,17 +326,17 @@ extern "C" int zpq_ctx_set_max_block_bytes(zpq_ctx *c, uint64_t bytes)
     c->sparse_cap = (uint32_t)cap;
     return ZPQ_OK;
 }
-extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return c ? c->last_slots : 0; }
-extern "C" unsigned zpq_ctx_last_line_store(const zpq_ctx *c) { return c ? c->last_sp : 0u; }
-extern "C" const char *zpq_ctx_last_kernel_name(const zpq_ctx *c) { return c ? c->last_name : ""; }
-extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c)
+extern "C" int zpq_ctx_last_slots(const zpq_ctx *c) { return ctx_live(c) ? c->last_slots : 0; }
+extern "C" unsigned zpq_ctx_last_line_store(const zpq_ctx *c) { return ctx_live(c) ? c->last_sp : 0u; }
+extern "C" const char *zpq_ctx_last_kernel_name(const zpq_ctx *c) { return ctx_live(c) ? c->last_name : ""; }
+extern "C" float zpq_ctx_last_kernel_ms(const zpq_ctx *c) try
 {
-    if (!c || !c->ev_valid) return -1.f;
+    if (!ctx_live(c) || !c->ev_valid) return -1.f;
     if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
     return ms;
-}
+} ZPQ_CATCH(return -1.f)
 
 static int get_dev_model(zpq_ctx *c, const zpq_model *m, const DModel &layout, uint32_t sparse_cap, DevModel *out)
 {
@@ -353,7 +405,7 @@ extern "C" int zpq_chain_touch_decode(const DModel *M);   // the decoder of this
 extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots);   // the wave-pipelined encoder codes this plan
 extern "C" int zpq_pipe_touch(void);                                                // ... and reads rows through the bitmaps (timing builds only)
 
-static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P, int decode = 0)
+static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblocks, bool trace, bool own_slot, Plan *P, int decode = 0) try
 {
     P->chain = m->d.fast_kind && !(flags & (ZPQ_FLAG_GENERIC | ZPQ_FLAG_LANES | ZPQ_FLAG_NOEOF | ZB_CTX_ONLY)) &&
                !trace && !own_slot && zpq_chain_blocks_per_wg(&m->d) > 0;
@@ -417,22 +469,23 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
     if (own_slot) { nslots = 1; grid = 1; }
     P->nslots = nslots; P->grid = grid; P->bpw = bpw;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" int zpq_ctx_resident_capacity(zpq_ctx *c, const zpq_model *m, uint32_t flags)
+extern "C" int zpq_ctx_resident_capacity(zpq_ctx *c, const zpq_model *m, uint32_t flags) try
 {
-    if (!c || !m) return ZPQ_E_ARG;
+    if (!ctx_live(c) || !m) return ZPQ_E_ARG;
     // the largest batch that both directions code in ONE round (a general model's encoder -- a wave per component -- holds more
     // blocks per CU than its decoder)
     Plan P, Q;
     int rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &P, 0);
     if (rc == ZPQ_OK) rc = plan_batch(c, m, flags & 0xffu, 1 << 30, false, false, &Q, 1);
     return rc != ZPQ_OK ? rc : (P.nslots < Q.nslots ? P.nslots : Q.nslots);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs &a)
 {
-    if (!c || !m) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (!m) return ZPQ_E_ARG;
     if (a.nblocks < 0) return ZPQ_E_ARG;
     if (a.nblocks == 0) return ZPQ_OK;
     if (!a.in_off || !a.out_off || !a.out_len || !a.status) return ZPQ_E_ARG;
@@ -466,7 +519,7 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
     if (a.own_slot) {
         B.slots = a.own_slot;
     } else {
-        rc = c->slots.ensure((size_t)nslots * M.slot_bytes + 256);   // (+256: zpq_gpipe.hip reads a MIX row as eight words whatever its length)
+        rc = c->slots.ensure((size_t)nslots * M.slot_bytes + 256);   // (the slack a MIX row read needs is part of slot_bytes: zpq_model.cpp mix_row_pad)
         if (rc != ZPQ_OK) return rc;
         B.slots = (uint8_t *)c->slots.p;
     }
@@ -504,22 +557,22 @@ static int run_batch(zpq_ctx *c, const zpq_model *m, int decode, const BatchArgs
 
 extern "C" int zpq_encode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
                                      const uint64_t *in_off, uint32_t flags, uint8_t *out,
-                                     const uint64_t *out_off, uint32_t *out_len, int32_t *status)
+                                     const uint64_t *out_off, uint32_t *out_len, int32_t *status) try
 {
     BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr, nullptr,
                    status, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0};
     return run_batch(c, m, 0, a);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 extern "C" int zpq_decode_blocks_dev(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
                                      const uint64_t *in_off, uint32_t flags, uint8_t *out,
                                      const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
-                                     uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+                                     uint32_t *final_code, uint32_t *first_byte, int32_t *status) try
 {
     BatchArgs a = {nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed, final_code,
                    first_byte, status, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0};
     return run_batch(c, m, 1, a);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ host-pointer forms
 static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, const uint8_t *in, const uint64_t *in_off,
@@ -531,7 +584,8 @@ static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, c
                       uint32_t *first_byte, int32_t *status, uint8_t *own_slot, int32_t *trace,
                       uint32_t ntrace, uint32_t *ctx_out, size_t ctx_words)
 {
-    if (!c || !m || nblocks < 0) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (!m || nblocks < 0) return ZPQ_E_ARG;
     if (nblocks == 0) return ZPQ_OK;
     if (!in_off || !out_off || !out_len || !status) return ZPQ_E_ARG;
     for (int b = 0; b < nblocks; b++)
@@ -592,13 +646,16 @@ static int host_batch(zpq_ctx *c, const zpq_model *m, int decode, int nblocks, c
 }
 
 // ------------------------------------------------------------------ pinned host memory + pipelined host batches
-extern "C" void *zpq_host_alloc(size_t bytes)
+extern "C" void *zpq_host_alloc(size_t bytes) try
 {
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
-}
-extern "C" void zpq_host_free(void *p) { if (p) (void)hipHostFree(p); }
+} ZPQ_CATCH(return nullptr)
+extern "C" void zpq_host_free(void *p) try
+{
+    if (p) (void)hipHostFree(p);
+} ZPQ_CATCH(return)
 
 // device-visible address of a host buffer if it is pinned (zpq_host_alloc / hipHostMalloc / hipHostRegister), else null
 static void *pinned_device_ptr(const void *p)
@@ -777,20 +834,20 @@ static int host_pipeline(zpq_ctx *c, const zpq_model *m, int decode, int nblocks
 
 extern "C" int zpq_encode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
                                  const uint64_t *in_off, uint32_t flags, uint8_t *out,
-                                 const uint64_t *out_off, uint32_t *out_len, int32_t *status)
+                                 const uint64_t *out_off, uint32_t *out_len, int32_t *status) try
 {
     return host_batch(c, m, 0, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr,
                       nullptr, status, nullptr, nullptr, 0, nullptr, 0);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 extern "C" int zpq_decode_blocks(zpq_ctx *c, const zpq_model *m, int nblocks, const uint8_t *in,
                                  const uint64_t *in_off, uint32_t flags, uint8_t *out,
                                  const uint64_t *out_off, uint32_t *out_len, uint32_t *consumed,
-                                 uint32_t *final_code, uint32_t *first_byte, int32_t *status)
+                                 uint32_t *final_code, uint32_t *first_byte, int32_t *status) try
 {
     return host_batch(c, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed,
                       final_code, first_byte, status, nullptr, nullptr, 0, nullptr, 0);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ several GPUs behind one call
 // Blocks are independent (compressor.v:90,147-148: fresh Predictor/ZPAQL per block), so any static deal gives the same
@@ -822,18 +879,18 @@ static int multi_batch(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int d
 
 extern "C" int zpq_encode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int nblocks, const uint8_t *in,
                                        const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
-                                       uint32_t *out_len, int32_t *status)
+                                       uint32_t *out_len, int32_t *status) try
 {
     return multi_batch(ctxs, nctx, m, 0, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, nullptr, nullptr, nullptr, status);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 extern "C" int zpq_decode_blocks_multi(zpq_ctx *const *ctxs, int nctx, const zpq_model *m, int nblocks, const uint8_t *in,
                                        const uint64_t *in_off, uint32_t flags, uint8_t *out, const uint64_t *out_off,
                                        uint32_t *out_len, uint32_t *consumed, uint32_t *final_code, uint32_t *first_byte,
-                                       int32_t *status)
+                                       int32_t *status) try
 {
     return multi_batch(ctxs, nctx, m, 1, nblocks, in, in_off, flags & 0xffu, out, out_off, out_len, consumed, final_code, first_byte, status);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ slab compaction
 // out_len[b] bytes of each capacity-strided output slab -> one dense buffer, so that only real
@@ -877,38 +934,42 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *src, const uint64
 }
 
 extern "C" int zpq_gather_dev(zpq_ctx *c, int nblocks, const uint8_t *src, const uint64_t *src_off, const uint32_t *len,
-                              uint8_t *dst, const uint64_t *dst_off)
+                              uint8_t *dst, const uint64_t *dst_off) try
 {
-    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (nblocks < 0) return ZPQ_E_ARG;
     if (nblocks == 0) return ZPQ_OK;
     if (!src_off || !len || !dst_off) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_gather, dim3(nblocks), dim3(256), 0, c->stream, src, src_off, len, dst, dst_off, nblocks, 0u);
     return hipGetLastError() == hipSuccess ? ZPQ_OK : ZPQ_E_INTERNAL;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ SHA-1 side kernel (sha1.v:6-146)
-extern "C" int zpq_sha1_blocks_dev(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20)
+extern "C" int zpq_sha1_blocks_dev(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20) try
 {
-    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (nblocks < 0) return ZPQ_E_ARG;
     if (nblocks == 0) return ZPQ_OK;
     if (!in_off || !out20) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
     return zpq_launch_sha1(in, in_off, in_off + 1, nblocks, out20, c->stream);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" int zpq_sha1_ranges_dev(zpq_ctx *c, int nranges, const uint8_t *in, const uint64_t *begin, const uint64_t *end, uint8_t *out20)
+extern "C" int zpq_sha1_ranges_dev(zpq_ctx *c, int nranges, const uint8_t *in, const uint64_t *begin, const uint64_t *end, uint8_t *out20) try
 {
-    if (!c || nranges < 0) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (nranges < 0) return ZPQ_E_ARG;
     if (nranges == 0) return ZPQ_OK;
     if (!begin || !end || !out20) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
     return zpq_launch_sha1(in, begin, end, nranges, out20, c->stream);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" int zpq_sha1_blocks(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20)
+extern "C" int zpq_sha1_blocks(zpq_ctx *c, int nblocks, const uint8_t *in, const uint64_t *in_off, uint8_t *out20) try
 {
-    if (!c || nblocks < 0) return ZPQ_E_ARG;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (nblocks < 0) return ZPQ_E_ARG;
     if (nblocks == 0) return ZPQ_OK;
     if (!in_off || !out20) return ZPQ_E_ARG;
     for (int b = 0; b < nblocks; b++) if (in_off[b + 1] < in_off[b]) return ZPQ_E_ARG;
@@ -930,34 +991,53 @@ extern "C" int zpq_sha1_blocks(zpq_ctx *c, int nblocks, const uint8_t *in, const
     HIPCK(hipMemcpyAsync(out20, c->s_out.p, (size_t)nblocks * 20, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ one block, many segments
-extern "C" int zpq_block_create(zpq_ctx *c, const zpq_model *m, zpq_block **out)
+extern "C" int zpq_block_create(zpq_ctx *c, const zpq_model *m, zpq_block **out) try
 {
-    if (!c || !m || !out) return ZPQ_E_ARG;
+    if (!out) return ZPQ_E_ARG;
     *out = nullptr;
+    if (!ctx_live(c)) return c ? ZPQ_E_CLOSED : ZPQ_E_ARG;
+    if (!m) return ZPQ_E_ARG;
     HIPCK(hipSetDevice(c->device));
     zpq_block *b = new (std::nothrow) zpq_block();
     if (!b) return ZPQ_E_NOMEM;
     b->ctx = c; b->model = m; b->fresh = true; b->slot = nullptr;
-    if (hipMalloc((void **)&b->slot, m->d.slot_bytes) != hipSuccess) { delete b; return ZPQ_E_NOMEM; }
+    if (hipMalloc((void **)&b->slot, m->d.slot_bytes) != hipSuccess) { (void)hipGetLastError(); delete b; return ZPQ_E_NOMEM; }
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (!live_set().count(c)) { (void)hipFree(b->slot); delete b; return ZPQ_E_CLOSED; }
+        c->children.push_back(b);
+    }
+    zpq_model_retain(m);
     *out = b;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" void zpq_block_destroy(zpq_block *b)
+extern "C" void zpq_block_destroy(zpq_block *b) try
 {
     if (!b) return;
-    (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->slot);
+    zpq_ctx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        c = b->ctx;                                         // nullptr: the ctx went first and took the slot with it
+        if (c) c->children.erase(std::remove(c->children.begin(), c->children.end(), b), c->children.end());
+        b->ctx = nullptr;
+    }
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (b->slot) (void)hipFree(b->slot);
+    }
+    zpq_model_release(b->model);
     delete b;
-}
+} ZPQ_CATCH(return)
 
 // replay the first segment into b->slot (see zpq_block): encode with no output room -- the coder only counts
 static int block_materialise(zpq_block *b)
 {
+    if (!b->ctx) return ZPQ_E_CLOSED;
     if (!b->lazy) return ZPQ_OK;
     const uint64_t in_off[2] = {0, b->lazy_in.size()}, out_off[2] = {0, 0};
     uint32_t olen = 0;
@@ -974,9 +1054,10 @@ static int block_materialise(zpq_block *b)
 }
 
 extern "C" int zpq_block_encode_segment(zpq_block *b, const uint8_t *in, size_t n, uint32_t flags,
-                                        uint8_t *out, size_t cap, size_t *out_len)
+                                        uint8_t *out, size_t cap, size_t *out_len) try
 {
     if (!b || !out_len || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    if (!b->ctx) return ZPQ_E_CLOSED;                   // the block's ctx has been destroyed
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
     uint32_t olen = 0;
     int32_t st = 0;
@@ -1000,13 +1081,14 @@ extern "C" int zpq_block_encode_segment(zpq_block *b, const uint8_t *in, size_t 
     b->fresh = false;
     *out_len = olen;
     return st;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 extern "C" int zpq_block_decode_segment(zpq_block *b, const uint8_t *in, size_t n, uint32_t flags,
                                         uint8_t *out, size_t cap, size_t *out_len, size_t *consumed,
-                                        uint32_t *final_code, uint32_t *first_byte)
+                                        uint32_t *final_code, uint32_t *first_byte) try
 {
     if (!b || !out_len || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    if (!b->ctx) return ZPQ_E_CLOSED;                   // the block's ctx has been destroyed
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
     uint32_t olen = 0, cons = 0, code = 0, first = 0xFFFFFFFFu;
     int32_t st = 0;
@@ -1043,12 +1125,12 @@ extern "C" int zpq_block_decode_segment(zpq_block *b, const uint8_t *in, size_t 
     if (final_code) *final_code = code;
     if (first_byte) *first_byte = first;
     return st;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // ------------------------------------------------------------------ test hooks
-extern "C" int zpq_debug_contexts(zpq_ctx *c, const zpq_model *m, const uint8_t *in, size_t n, uint32_t *h_out)
+extern "C" int zpq_debug_contexts(zpq_ctx *c, const zpq_model *m, const uint8_t *in, size_t n, uint32_t *h_out) try
 {
-    if (!c || !m || !h_out || (n && !in)) return ZPQ_E_ARG;
+    if (!ctx_live(c) || !m || !h_out || (n && !in)) return ZPQ_E_ARG;
     if (m->d.n == 0 || n == 0) return ZPQ_OK;
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, 0};
     uint32_t olen = 0;
@@ -1057,13 +1139,13 @@ extern "C" int zpq_debug_contexts(zpq_ctx *c, const zpq_model *m, const uint8_t 
     int rc = host_batch(c, m, 0, 1, in, in_off, ZPQ_FLAG_GENERIC | ZB_CTX_ONLY, &dummy, out_off, &olen,
                         nullptr, nullptr, nullptr, &st, nullptr, nullptr, 0, h_out, n * (size_t)m->d.n);
     return rc != ZPQ_OK ? rc : st;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 extern "C" int zpq_debug_encode_trace(zpq_ctx *c, const zpq_model *m, const uint8_t *in, size_t n,
                                       uint32_t flags, uint8_t *out, size_t cap, size_t *out_len,
-                                      int32_t *p_trace, size_t ntrace)
+                                      int32_t *p_trace, size_t ntrace) try
 {
-    if (!c || !m || !out_len || !p_trace || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
+    if (!ctx_live(c) || !m || !out_len || !p_trace || (n && !in) || (cap && !out)) return ZPQ_E_ARG;
     const uint64_t in_off[2] = {0, n}, out_off[2] = {0, cap};
     uint32_t olen = 0;
     int32_t st = 0;
@@ -1072,4 +1154,4 @@ extern "C" int zpq_debug_encode_trace(zpq_ctx *c, const zpq_model *m, const uint
     if (rc != ZPQ_OK) return rc;
     *out_len = olen;
     return st;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)

@@ -25,6 +25,7 @@
 #include <thread>
 
 #include "../../include/zpaq_frontend.hpp"
+#include "zpq_host.h"
 
 namespace zpaq {
 
@@ -740,56 +741,81 @@ static int decode_groups(zpq_ctx *ctx, const uint8_t *arc, size_t n, bool want_d
 }  // namespace zpaq
 
 // ------------------------------------------------------------------ flat C surface for ctypes
+// (C++ exceptions stop here: *rc = ZPQ_E_INTERNAL / ZPQ_E_NOMEM and an empty handle, never an abort)
 struct zpqf_archive {
     std::vector<uint8_t> bytes;
     std::vector<zpaq::ArchiveFile> files;
 };
 
+namespace {
+template <class F> zpqf_archive *archive_call(int *rc, const char *where, F &&f) noexcept
+{
+    zpqf_archive *h = nullptr;
+    int r = ZPQ_E_INTERNAL;
+    try {
+        h = new zpqf_archive();
+        r = f(h);
+    } catch (const std::bad_alloc &) {
+        zpq_note_exception(where);
+        r = ZPQ_E_NOMEM;
+    } catch (...) {
+        zpq_note_exception(where);
+        r = ZPQ_E_INTERNAL;
+    }
+    if (rc) *rc = r;
+    return h;
+}
+const zpaq::ArchiveFile *file_at(zpqf_archive *h, int i) { return (h && i >= 0 && (size_t)i < h->files.size()) ? &h->files[(size_t)i] : nullptr; }
+}  // namespace
+
 extern "C" {
 zpqf_archive *zpqf_archive_add_fragmented(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
                                           const uint8_t *const *data, const uint64_t *lens, uint64_t fragment_bytes, int *rc)
 {
-    zpqf_archive *h = new zpqf_archive();
-    const int r = zpaq::archive_add_views(std::vector<zpq_ctx *>{ctx}, level, nfiles, names, comments, data, lens, &h->bytes, (size_t)fragment_bytes);
-    if (rc) *rc = r;
-    return h;
+    return archive_call(rc, __func__, [&](zpqf_archive *h) {
+        return zpaq::archive_add_views(std::vector<zpq_ctx *>{ctx}, level, nfiles, names, comments, data, lens, &h->bytes, (size_t)fragment_bytes);
+    });
 }
 zpqf_archive *zpqf_archive_add_multi(zpq_ctx *const *ctxs, int nctx, int level, int nfiles, const char *const *names,
                                      const char *const *comments, const uint8_t *const *data, const uint64_t *lens,
                                      uint64_t fragment_bytes, int *rc)
 {
-    zpqf_archive *h = new zpqf_archive();
-    const int r = zpaq::archive_add_views(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), level, nfiles, names, comments, data, lens, &h->bytes,
-                                          (size_t)fragment_bytes);
-    if (rc) *rc = r;
-    return h;
+    return archive_call(rc, __func__, [&](zpqf_archive *h) {
+        if (!ctxs || nctx <= 0) return (int)ZPQ_E_ARG;
+        return zpaq::archive_add_views(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), level, nfiles, names, comments, data, lens, &h->bytes,
+                                       (size_t)fragment_bytes);
+    });
 }
 zpqf_archive *zpqf_archive_extract_multi(zpq_ctx *const *ctxs, int nctx, const uint8_t *arc, size_t n, int want_data, int *rc)
 {
-    zpqf_archive *h = new zpqf_archive();
-    const int r = zpaq::archive_extract(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
-    if (rc) *rc = r;
-    return h;
+    return archive_call(rc, __func__, [&](zpqf_archive *h) {
+        if (!ctxs || nctx <= 0) return (int)ZPQ_E_ARG;
+        return zpaq::archive_extract(std::vector<zpq_ctx *>(ctxs, ctxs + nctx), arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
+    });
 }
 zpqf_archive *zpqf_archive_add(zpq_ctx *ctx, int level, int nfiles, const char *const *names, const char *const *comments,
                                const uint8_t *const *data, const uint64_t *lens, int *rc)
 {
     return zpqf_archive_add_fragmented(ctx, level, nfiles, names, comments, data, lens, 0, rc);
 }
-size_t zpqf_archive_bytes(zpqf_archive *h, const uint8_t **p) { *p = h->bytes.data(); return h->bytes.size(); }
+size_t zpqf_archive_bytes(zpqf_archive *h, const uint8_t **p)
+{
+    if (!h || !p) return 0;
+    *p = h->bytes.data();
+    return h->bytes.size();
+}
 zpqf_archive *zpqf_archive_extract(zpq_ctx *ctx, const uint8_t *arc, size_t n, int want_data, int *rc)
 {
-    zpqf_archive *h = new zpqf_archive();
-    const int r = zpaq::archive_extract(ctx, arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
-    if (rc) *rc = r;
-    return h;
+    return archive_call(rc, __func__, [&](zpqf_archive *h) {
+        return zpaq::archive_extract(ctx, arc, n, (want_data & 1) != 0, &h->files, (want_data & 2) != 0);
+    });
 }
-int zpqf_archive_nfiles(zpqf_archive *h) { return (int)h->files.size(); }
-const char *zpqf_archive_name(zpqf_archive *h, int i) { return h->files[(size_t)i].name.c_str(); }
-const char *zpqf_archive_comment(zpqf_archive *h, int i) { return h->files[(size_t)i].comment.c_str(); }
-uint64_t zpqf_archive_size(zpqf_archive *h, int i) { return h->files[(size_t)i].size; }
-int zpqf_archive_sha1_ok(zpqf_archive *h, int i) { return h->files[(size_t)i].sha1_ok ? 1 : 0; }
-int zpqf_archive_status(zpqf_archive *h, int i) { return h->files[(size_t)i].status; }
-const uint8_t *zpqf_archive_data(zpqf_archive *h, int i) { return h->files[(size_t)i].data.data(); }
-void zpqf_archive_free(zpqf_archive *h) { delete h; }
+int zpqf_archive_nfiles(zpqf_archive *h) { return h ? (int)h->files.size() : 0; }
+const char *zpqf_archive_name(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return f ? f->name.c_str() : ""; }
+const char *zpqf_archive_comment(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return f ? f->comment.c_str() : ""; }
+uint64_t zpqf_archive_size(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return f ? f->size : 0; }
+int zpqf_archive_sha1_ok(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return (f && f->sha1_ok) ? 1 : 0; }
+int zpqf_archive_status(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return f ? f->status : ZPQ_E_ARG; }
+const uint8_t *zpqf_archive_data(zpqf_archive *h, int i) { const zpaq::ArchiveFile *f = file_at(h, i); return f ? f->data.data() : nullptr; }
+void zpqf_archive_free(zpqf_archive *h) { zpq_guard_v(__func__, [&] { delete h; }); }
 }

@@ -1420,7 +1420,7 @@ extern "C" int zpq_chain_has_hio(const DModel *M)
 
 // zpq_pipe.hip: the wave-pipelined encoder of the chains without a MIX2
 extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots);
-extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream);
+extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream, const char **name_out);
 
 // zpq_dpipe.hip: the wave-split decoder of the dense chains without a MIX2
 extern "C" int zpq_dpipe_applies(const DModel *M, int blocks_per_wg, int nslots);
@@ -1436,8 +1436,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
     if (name_out) *name_out = decode ? "k_chain<decode>" : "k_chain<encode>";
     if (!decode && zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) {
-        if (name_out) *name_out = "k_pipe<encode>";
-        return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream);
+        return zpq_launch_pipe(B, hostM, nwg, blocks_per_wg, stream, name_out);   // "k_pipe<encode>" or "k_pipe2<encode>" (split stages)
     }
     if (decode && !B->prog_counter && zpq_dpipe_applies(hostM, blocks_per_wg, B->nslots)) {
         if (name_out) *name_out = "k_dpipe<decode>";

@@ -10,6 +10,7 @@
 // the GPU through zpq_block_encode_segment / zpq_block_decode_segment.
 #include "../../include/zpaq_frontend.hpp"
 #include "zpq_vm.h"
+#include "zpq_host.h"
 
 #include <string.h>
 
@@ -545,12 +546,15 @@ void Decompresser::read_segment_end()
 }  // namespace zpaq
 
 // ------------------------------------------------------------------ flat C surface for ctypes
+// Every entry point stops C++ exceptions here (std::bad_alloc from the staging vectors, anything the layers below let
+// through): a boolean call then answers "false" and last_error reports ZPQ_E_INTERNAL.
 using namespace zpaq;
 
 struct zpqf_comp {
     Compressor c;
     FileWriter out;
     FileReader *in;
+    int guard_err = ZPQ_OK;
     explicit zpqf_comp(zpq_ctx *ctx) : c(ctx), in(nullptr) { c.set_output(&out); }
     ~zpqf_comp() { delete in; }
 };
@@ -558,73 +562,102 @@ struct zpqf_decomp {
     Decompresser d;
     FileWriter out;
     FileReader *in;
+    int guard_err = ZPQ_OK;
     explicit zpqf_decomp(zpq_ctx *ctx) : d(ctx), in(nullptr) { d.set_output(&out); }
     ~zpqf_decomp() { delete in; }
 };
 
+namespace {
+template <class H, class F> void call_v(H *h, const char *where, F &&f) noexcept
+{
+    if (!h) return;
+    try { f(); } catch (...) { zpq_note_exception(where); h->guard_err = ZPQ_E_INTERNAL; }
+}
+template <class H, class F> int call_b(H *h, const char *where, F &&f) noexcept
+{
+    if (!h) return 0;
+    try { return f() ? 1 : 0; } catch (...) { zpq_note_exception(where); h->guard_err = ZPQ_E_INTERNAL; return 0; }
+}
+size_t copy_str(const std::string &s, char *buf, size_t cap)
+{
+    if (buf && cap) { const size_t k = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), k); buf[k] = 0; }
+    return s.size();
+}
+}  // namespace
+
 extern "C" {
-zpqf_comp *zpqf_compressor_new(zpq_ctx *ctx) { return new zpqf_comp(ctx); }
-void zpqf_compressor_free(zpqf_comp *h) { delete h; }
+zpqf_comp *zpqf_compressor_new(zpq_ctx *ctx) { return zpq_guard<zpqf_comp *>(nullptr, __func__, [&] { return new zpqf_comp(ctx); }); }
+void zpqf_compressor_free(zpqf_comp *h) { zpq_guard_v(__func__, [&] { delete h; }); }
 void zpqf_compressor_set_input(zpqf_comp *h, const uint8_t *p, size_t n)
 {
-    delete h->in;
-    h->in = new FileReader(std::vector<uint8_t>(p, p + n));
-    h->c.set_input(h->in);
+    call_v(h, __func__, [&] {
+        delete h->in;
+        h->in = nullptr;
+        h->in = new FileReader(std::vector<uint8_t>(p, p + n));
+        h->c.set_input(h->in);
+    });
 }
-void zpqf_compressor_start_block(zpqf_comp *h, int level) { h->c.start_block(level); }
+void zpqf_compressor_start_block(zpqf_comp *h, int level) { call_v(h, __func__, [&] { h->c.start_block(level); }); }
 void zpqf_compressor_start_block_hcomp(zpqf_comp *h, const uint8_t *p, size_t n)
 {
-    h->c.start_block_hcomp(std::string((const char *)p, n));
+    call_v(h, __func__, [&] { h->c.start_block_hcomp(std::string((const char *)p, n)); });
 }
-void zpqf_compressor_start_segment(zpqf_comp *h, const char *fn, const char *cm) { h->c.start_segment(fn, cm); }
-int zpqf_compressor_compress(zpqf_comp *h, int n) { return h->c.compress(n) ? 1 : 0; }
-void zpqf_compressor_end_segment(zpqf_comp *h) { h->c.end_segment(); }
-void zpqf_compressor_end_block(zpqf_comp *h) { h->c.end_block(); }
-int zpqf_compressor_last_error(zpqf_comp *h) { return h->c.last_error(); }
+void zpqf_compressor_start_segment(zpqf_comp *h, const char *fn, const char *cm) { call_v(h, __func__, [&] { h->c.start_segment(fn ? fn : "", cm ? cm : ""); }); }
+int zpqf_compressor_compress(zpqf_comp *h, int n) { return call_b(h, __func__, [&] { return h->c.compress(n); }); }
+void zpqf_compressor_end_segment(zpqf_comp *h) { call_v(h, __func__, [&] { h->c.end_segment(); }); }
+void zpqf_compressor_end_block(zpqf_comp *h) { call_v(h, __func__, [&] { h->c.end_block(); }); }
+int zpqf_compressor_last_error(zpqf_comp *h) { return !h ? ZPQ_E_ARG : h->guard_err != ZPQ_OK ? h->guard_err : h->c.last_error(); }
 size_t zpqf_compressor_output(zpqf_comp *h, const uint8_t **p)
 {
+    if (!h || !p) return 0;
     *p = h->out.bytes().data();
     return h->out.bytes().size();
 }
 void zpqf_compressor_sha1(zpqf_comp *h, uint8_t out20[20])
 {
-    const std::vector<uint8_t> r = h->c.get_sha1();
-    memcpy(out20, r.data(), 20);
+    call_v(h, __func__, [&] {
+        const std::vector<uint8_t> r = h->c.get_sha1();
+        memcpy(out20, r.data(), 20);
+    });
 }
 
-zpqf_decomp *zpqf_decompresser_new(zpq_ctx *ctx) { return new zpqf_decomp(ctx); }
-void zpqf_decompresser_free(zpqf_decomp *h) { delete h; }
+zpqf_decomp *zpqf_decompresser_new(zpq_ctx *ctx) { return zpq_guard<zpqf_decomp *>(nullptr, __func__, [&] { return new zpqf_decomp(ctx); }); }
+void zpqf_decompresser_free(zpqf_decomp *h) { zpq_guard_v(__func__, [&] { delete h; }); }
 void zpqf_decompresser_set_input(zpqf_decomp *h, const uint8_t *p, size_t n)
 {
-    delete h->in;
-    h->in = new FileReader(std::vector<uint8_t>(p, p + n));
-    h->d.set_input(h->in);
+    call_v(h, __func__, [&] {
+        delete h->in;
+        h->in = nullptr;
+        h->in = new FileReader(std::vector<uint8_t>(p, p + n));
+        h->d.set_input(h->in);
+    });
 }
-int zpqf_decompresser_find_block(zpqf_decomp *h) { return h->d.find_block() ? 1 : 0; }
-int zpqf_decompresser_find_filename(zpqf_decomp *h) { return h->d.find_filename() ? 1 : 0; }
+int zpqf_decompresser_find_block(zpqf_decomp *h) { return call_b(h, __func__, [&] { return h->d.find_block(); }); }
+int zpqf_decompresser_find_filename(zpqf_decomp *h) { return call_b(h, __func__, [&] { return h->d.find_filename(); }); }
 size_t zpqf_decompresser_filename(zpqf_decomp *h, char *buf, size_t cap)
 {
-    const std::string s = h->d.get_filename();
-    if (cap) { const size_t k = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), k); buf[k] = 0; }
-    return s.size();
+    if (!h) return 0;
+    return zpq_guard<size_t>(0, __func__, [&] { return copy_str(h->d.get_filename(), buf, cap); });
 }
 size_t zpqf_decompresser_comment(zpqf_decomp *h, char *buf, size_t cap)
 {
-    const std::string s = h->d.get_comment();
-    if (cap) { const size_t k = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), k); buf[k] = 0; }
-    return s.size();
+    if (!h) return 0;
+    return zpq_guard<size_t>(0, __func__, [&] { return copy_str(h->d.get_comment(), buf, cap); });
 }
-int zpqf_decompresser_decompress(zpqf_decomp *h, int n) { return h->d.decompress(n) ? 1 : 0; }
-void zpqf_decompresser_read_segment_end(zpqf_decomp *h) { h->d.read_segment_end(); }
-int zpqf_decompresser_last_error(zpqf_decomp *h) { return h->d.last_error(); }
+int zpqf_decompresser_decompress(zpqf_decomp *h, int n) { return call_b(h, __func__, [&] { return h->d.decompress(n); }); }
+void zpqf_decompresser_read_segment_end(zpqf_decomp *h) { call_v(h, __func__, [&] { h->d.read_segment_end(); }); }
+int zpqf_decompresser_last_error(zpqf_decomp *h) { return !h ? ZPQ_E_ARG : h->guard_err != ZPQ_OK ? h->guard_err : h->d.last_error(); }
 size_t zpqf_decompresser_output(zpqf_decomp *h, const uint8_t **p)
 {
+    if (!h || !p) return 0;
     *p = h->out.bytes().data();
     return h->out.bytes().size();
 }
 void zpqf_decompresser_sha1(zpqf_decomp *h, uint8_t out20[20])
 {
-    const std::vector<uint8_t> r = h->d.get_sha1();
-    memcpy(out20, r.data(), 20);
+    call_v(h, __func__, [&] {
+        const std::vector<uint8_t> r = h->d.get_sha1();
+        memcpy(out20, r.data(), 20);
+    });
 }
 }

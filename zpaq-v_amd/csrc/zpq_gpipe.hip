@@ -1429,6 +1429,16 @@ extern "C" int zpq_gpipe_applies(const DModel *M)
     return gpipe_cfg(M, &cfg, &lds) ? 1 : 0;
 }
 
+// Workgroups of `threads` threads and `lds` bytes that one CU keeps resident: what the runtime says for the compiled kernel
+// (registers included), never more than the hand calculation `bound`; the hand calculation alone where the query fails.
+static int occupancy_wgs(const void *fn, int threads, size_t lds, int bound)
+{
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); return bound; }
+    return nb < bound ? nb : bound;
+}
+
 extern "C" int zpq_gpipe_blocks_per_cu(const DModel *M)
 {
     zpqg::GCfg cfg;
@@ -1436,8 +1446,11 @@ extern "C" int zpq_gpipe_blocks_per_cu(const DModel *M)
     if (!gpipe_cfg(M, &cfg, &lds)) return 0;
     const int wgs = (int)((160 * 1024) / lds);                 // workgroups per CU by LDS; waves: n + 1 of the 16 that 128 VGPRs allow
     const int by_waves = 16 / (cfg.n + 1);
-    const int w = wgs < by_waves ? wgs : by_waves;
-    return (w < 1 ? 1 : w) * zpqg::BPW;
+    int w = wgs < by_waves ? wgs : by_waves;
+    if (w < 1) w = 1;
+    const int threads = 64 * (cfg.n + 1);
+    const int a = occupancy_wgs((const void *)zpqg::k_gpipe<true>, threads, lds, w), b = occupancy_wgs((const void *)zpqg::k_gpipe<false>, threads, lds, w);
+    return (a < b ? a : b) * zpqg::BPW;
 }
 
 extern "C" int zpq_launch_gpipe(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream)
@@ -1480,7 +1493,7 @@ extern "C" int zpq_gdec_blocks_per_cu(const DModel *M)
     zpqg::GCfg cfg;
     size_t lds = 0, dlds = 0;
     if (!gpipe_cfg(M, &cfg, &lds, &dlds)) return 0;
-    return gdec_wgs_per_cu(cfg, dlds) * zpqg::BPW;
+    return occupancy_wgs((const void *)zpqg::k_gdec, 64 * (cfg.n + 1), dlds, gdec_wgs_per_cu(cfg, dlds)) * zpqg::BPW;
 }
 
 extern "C" int zpq_launch_gdec(const DBatch *B, const DModel *hostM, int nslots, hipStream_t stream)

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "zpq_common.h"
@@ -42,4 +43,24 @@ struct zpq_model {
     DModel d;
     std::vector<uint32_t> img;  // initial table contents (ICM/ISSE/SSE), uploaded per ctx
     uint64_t id;                // unique, for the per-ctx device cache
+    mutable std::atomic<int> refs{1};   // the creator's handle + one per zpq_block built on it: zpq_model_destroy only drops the creator's
 };
+void zpq_model_retain(const zpq_model *m);
+void zpq_model_release(const zpq_model *m);   // deletes the model with its last reference
+
+// ---- the C boundary never lets a C++ exception out (include/zpaq_hip.h: "never aborts, no exceptions").  Every
+// extern "C" definition is a function-try-block:   extern "C" int f(...) try { ... } ZPQ_CATCH(return ZPQ_E_INTERNAL)
+// std::bad_alloc and std::system_error can come from the containers and threads of the host code; the HIP runtime itself
+// has been seen to throw (std::bad_variant_access out of a call on a stream whose owner was gone).
+void zpq_note_exception(const char *where) noexcept;
+#define ZPQ_CATCH(on_error) catch (...) { zpq_note_exception(__func__); on_error; }
+
+// the same for one-line entry points:  return zpq_guard<int>(0, __func__, [&] { ... });
+template <class R, class F> static inline R zpq_guard(R on_error, const char *where, F &&f) noexcept
+{
+    try { return f(); } catch (...) { zpq_note_exception(where); return on_error; }
+}
+template <class F> static inline void zpq_guard_v(const char *where, F &&f) noexcept
+{
+    try { f(); } catch (...) { zpq_note_exception(where); }
+}

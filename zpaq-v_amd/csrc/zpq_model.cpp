@@ -237,7 +237,7 @@ using namespace zpq;
 
 // ---------------------------------------------------------------- C ABI (no GPU needed)
 
-extern "C" int zpq_scan_header(const uint8_t *h, int len, int *cend, int *hbegin, int *hend)
+extern "C" int zpq_scan_header(const uint8_t *h, int len, int *cend, int *hbegin, int *hend) try
 {
     if (!h || len < 0 || !cend || !hbegin || !hend) return ZPQ_E_ARG;
     if (len < 5) { *cend = *hbegin = *hend = len; return ZPQ_OK; }   // compressor.v:141-145
@@ -256,9 +256,9 @@ extern "C" int zpq_scan_header(const uint8_t *h, int len, int *cend, int *hbegin
     }
     *hend = pos;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" int zpq_level_header(int level, uint8_t *buf, int cap, int *len, int *cend, int *hbegin, int *hend)
+extern "C" int zpq_level_header(int level, uint8_t *buf, int cap, int *len, int *cend, int *hbegin, int *hend) try
 {
     // levels.v:40-375: the six literal headers.  Levels 2..5 share one shape:
     // ICM + ISSE chain (+ MIX2), contexts from "b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt".
@@ -290,13 +290,20 @@ extern "C" int zpq_level_header(int level, uint8_t *buf, int cap, int *len, int 
     if (hbegin) *hbegin = b;
     if (hend) *hend = c;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 static std::atomic<uint64_t> g_model_ids{1};
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+// zpq_gpipe.hip reads every MIX weight row as eight words whatever m is (no branch around a load): up to 28 bytes past the
+// row.  The spare bytes belong to the LAYOUT, so that any slot provider (the ctx pool, a zpq_block's own slot) has them.
+static uint64_t mix_row_pad(const DModel &D)
+{
+    for (int i = 0; i < D.n; i++) if (D.comp[i].type == ZT_MIX) return 32;
+    return 0;
+}
 
-extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegin, int hend, zpq_model **out)
+extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegin, int hend, zpq_model **out) try
 {
     if (!out || len < 0 || (len > 0 && !hdr)) return ZPQ_E_ARG;
     *out = nullptr;
@@ -421,12 +428,12 @@ extern "C" int zpq_model_create(const uint8_t *hdr, int len, int cend, int hbegi
     if (i < n) fast = false;   // components past cend stay type 0 (quirk Q14)
     if (n > 0 && D.comp[0].type != ZT_ICM) fast = false;
     D.fast_kind = fast ? 1u : 0u;
-    D.slot_bytes = align_up(off, 256);
+    D.slot_bytes = align_up(off + mix_row_pad(D), 256);
     D.zero_bytes = D.slot_bytes;
     D.img_words = (uint32_t)img.size();
     *out = m;
     return ZPQ_OK;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
 // Compact line store layout.  A block of N bytes probes each hash table 2(N+1) times, so it
 // can touch at most that many 64-byte lines; the dense table (64 << sizebits bytes: 256 MiB at
@@ -467,7 +474,7 @@ bool zpq_sparse_layout(const DModel &dense, uint32_t cap, DModel *out)
         DComp &c = D.comp[i];
         if (c.sp_cap) c.sp_line_off = take(64ull * cap);
     }
-    D.slot_bytes = align_up(off, 256);
+    D.slot_bytes = align_up(off + mix_row_pad(D), 256);
     return any;
 }
 
@@ -495,20 +502,30 @@ bool zpq_touch_layout(const DModel &dense, DModel *out)
         DComp &c = D.comp[i];
         if (c.tb_off) c.ht_off = take(c.ht_len);
     }
-    D.slot_bytes = align_up(off, 256);
+    D.slot_bytes = align_up(off + mix_row_pad(D), 256);
     return any;
 }
 
-extern "C" int zpq_model_create_level(int level, zpq_model **out)
+extern "C" int zpq_model_create_level(int level, zpq_model **out) try
 {
     uint8_t h[128];
     int len = 0, a = 0, b = 0, c = 0;
     const int rc = zpq_level_header(level, h, (int)sizeof h, &len, &a, &b, &c);
     if (rc != ZPQ_OK) return rc;
     return zpq_model_create(h, len, a, b, c, out);
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" void zpq_model_destroy(zpq_model *m) { delete m; }
+void zpq_model_retain(const zpq_model *m) { if (m) m->refs.fetch_add(1, std::memory_order_relaxed); }
+void zpq_model_release(const zpq_model *m)
+{
+    if (m && m->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete m;
+}
+// Drops the creator's reference; a zpq_block built on the model keeps it alive until the block goes (handles may be
+// dropped in any order).
+extern "C" void zpq_model_destroy(zpq_model *m) try
+{
+    zpq_model_release(m);
+} ZPQ_CATCH(return)
 extern "C" int zpq_model_ncomp(const zpq_model *m) { return m ? m->d.n : 0; }
 int zpq_vm_hashchain(const DModel *M)
 {
@@ -529,16 +546,28 @@ int zpq_vm_hashchain(const DModel *M)
 extern "C" uint64_t zpq_model_state_bytes(const zpq_model *m) { return m ? m->d.slot_bytes : 0; }
 extern "C" int zpq_model_has_fast_path(const zpq_model *m) { return m ? (int)m->d.fast_kind : 0; }
 
-extern "C" int zpq_tables(int32_t *squash4096, int32_t *stretch32768)
+extern "C" int zpq_tables(int32_t *squash4096, int32_t *stretch32768) try
 {
     int st = ZPQ_OK;
     const Tables &T = tables(&st);
     if (squash4096) memcpy(squash4096, T.squash, sizeof T.squash);
     if (stretch32768) memcpy(stretch32768, T.stretch, sizeof T.stretch);
     return st;
-}
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
 
-extern "C" const char *zpq_status_string(int code)
+// dt (predictor.v:111-166), dt2k (predictor.v:99-106) and the StateTable's ns[1024] (statetable.v:15-57) as this library
+// builds them; tests hold them equal to the reference's literals (tests/golden/reference_literals.json).
+extern "C" int zpq_tables_ex(int32_t *dt1024, int32_t *dt2k256, uint8_t *ns1024) try
+{
+    int st = ZPQ_OK;
+    const Tables &T = tables(&st);
+    if (dt1024) memcpy(dt1024, T.dt, sizeof T.dt);
+    if (dt2k256) memcpy(dt2k256, T.dt2k, sizeof T.dt2k);
+    if (ns1024) memcpy(ns1024, T.ns, sizeof T.ns);
+    return st;
+} ZPQ_CATCH(return ZPQ_E_INTERNAL)
+
+extern "C" const char *zpq_status_string(int code) try
 {
     switch (code) {
     case ZPQ_OK: return "ok";
@@ -550,9 +579,10 @@ extern "C" const char *zpq_status_string(int code)
     case ZPQ_E_NOMEM: return "out of memory";
     case ZPQ_E_OVERFLOW: return "output slab too small";
     case ZPQ_E_VMSTEPS: return "ZPAQL step cap exceeded";
-    case ZPQ_E_INTERNAL: return "internal self-check failed";
+    case ZPQ_E_INTERNAL: return "internal error (self-check failed, or a C++ exception stopped at the C boundary)";
+    case ZPQ_E_CLOSED: return "the handle's context has been destroyed";
     default: return "unknown";
     }
-}
+} ZPQ_CATCH(return "")
 
 extern "C" const char *zpq_version(void) { return "zpaq-v_amd 0.1 (gfx950)"; }

@@ -537,7 +537,7 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
     const u32 total = S.total;
     InWin W;
     if (S.active) W.open(S.src, S.nin, B.in_off);
-    u32 prev = 0, m4 = 0, b4 = 0, hctx = 0;
+    u32 prev = 0, m4 = 0, b4 = 0;
     u32 slotn = 1;
     u32 ch = 0;
 #define ZPH_LOAD_ROWS(q_, po_)                                                          \
@@ -1229,8 +1229,29 @@ extern "C" int zpq_pipe_applies(const DModel *M, int blocks_per_wg, int nslots)
     return pipe_layout(cfg, blocks_per_wg, &L, &lds) ? 1 : 0;
 }
 
-extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream)
+// A wave -> role order for k_pipe2 is usable when every component c < nch is there exactly once, either whole (8 + c) or as
+// its history (2c) + weights (2c + 1) pair, and there is exactly one coder (6); anything else would index past the model's
+// components or leave out_len / status unwritten.
+static bool split_order_valid(const char *order, int nch)
 {
+    int whole[3] = {0, 0, 0}, hist[3] = {0, 0, 0}, pred[3] = {0, 0, 0}, coder = 0, nw = 0;
+    for (const char *q = order; *q; q++, nw++) {
+        const int id = *q == 'a' ? 10 : (*q >= '0' && *q <= '9') ? *q - '0' : -1;
+        if (id < 0 || id == 7) return false;
+        if (id == 6) { coder++; continue; }
+        const int c = id >= 8 ? id - 8 : id >> 1;
+        if (c >= nch || c > 2) return false;
+        if (id >= 8) whole[c]++; else if (id & 1) pred[c]++; else hist[c]++;
+    }
+    if (coder != 1 || nw > 2 * nch + 1) return false;
+    for (int c = 0; c < nch; c++)
+        if (!((whole[c] == 1 && !hist[c] && !pred[c]) || (!whole[c] && hist[c] == 1 && pred[c] == 1))) return false;
+    return true;
+}
+
+extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream, const char **name_out)
+{
+    if (name_out) *name_out = "k_pipe<encode>";
     Cfg cfg;
     if (!zpq_chain_build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     if (!zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) return ZPQ_E_INTERNAL;
@@ -1259,7 +1280,10 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
         cfg.split_enc = 0;
         if (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0 && strlen(ev) == 1)) {
             const char *order = cfg.nch_spec == 2 ? "60231" : nullptr;
-            if (ev && strlen(ev) >= 4 && strlen(ev) <= (size_t)(2 * cfg.nch_spec + 1) && strspn(ev, "012345689a") == strlen(ev)) order = ev;
+            if (ev && strlen(ev) >= 4) {
+                if (split_order_valid(ev, cfg.nch_spec)) order = ev;
+                else fprintf(stderr, "[zpaq_hip] ZPQ_ENC_SPLIT=%s is not a complete wave order for %d components: ignored\n", ev, cfg.nch_spec);
+            }
             if (order) {
                 uint64_t v = 0;
                 int mask = 0, nw = 0;
@@ -1292,6 +1316,7 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
         hipLaunchKernelGGL((zpqp::k_pipe2<N, HIOv>), dim3(nwg), dim3(64 * (int)((cfg.split_enc >> 40) & 15)), lds, stream, *B, cfg, L);  \
     } while (0)
     if (cfg.split_enc) {
+        if (name_out) *name_out = "k_pipe2<encode>";
         if (cfg.nch_spec == 2) { if (hio) ZPP_LAUNCH2(2, true); else ZPP_LAUNCH2(2, false); }
         else { if (hio) ZPP_LAUNCH2(3, true); else ZPP_LAUNCH2(3, false); }
         return ZPQ_OK;

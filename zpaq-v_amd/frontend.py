@@ -75,12 +75,20 @@ class Compressor:
     def __init__(self, ctx=None):
         self._L = _lib()
         self.h = self._L.zpqf_compressor_new(ctx.h if ctx is not None else None)
+        if not self.h:
+            raise B.ZpqError(-9, "zpqf_compressor_new")
         self._keep = None
+        if ctx is not None:
+            ctx._children.add(self)                        # closed before the ctx (binding.Context.close)
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "h", None) and B._LIB is not None:
             self._L.zpqf_compressor_free(self.h)
             self.h = None
+
+    def __del__(self):
+        if not B._FINALIZING:
+            self.close()
 
     def set_input(self, data):
         self._keep = bytes(data)
@@ -125,12 +133,20 @@ class Decompresser:
     def __init__(self, ctx=None):
         self._L = _lib()
         self.h = self._L.zpqf_decompresser_new(ctx.h if ctx is not None else None)
+        if not self.h:
+            raise B.ZpqError(-9, "zpqf_decompresser_new")
         self._keep = None
+        if ctx is not None:
+            ctx._children.add(self)
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "h", None) and B._LIB is not None:
             self._L.zpqf_decompresser_free(self.h)
             self.h = None
+
+    def __del__(self):
+        if not B._FINALIZING:
+            self.close()
 
     def set_input(self, data):
         self._keep = bytes(data)
@@ -192,8 +208,8 @@ def archive_add(ctx, level, files, fragment_bytes=0):
         h = L.zpqf_archive_add_fragmented(ctx.h if ctx is not None else None, level, n, names, comments, data, lens,
                                           fragment_bytes, C.byref(rc))
     try:
-        if rc.value != 0:
-            raise B.ZpqError(rc.value, "archive_add")
+        if rc.value != 0 or not h:
+            raise B.ZpqError(rc.value or -9, "archive_add")
         p = C.c_void_p()
         k = L.zpqf_archive_bytes(h, C.byref(p))
         return C.string_at(p, k) if k else b""
@@ -214,8 +230,8 @@ def archive_extract(ctx, archive, want_data=True, join_unnamed=False):
     else:
         h = L.zpqf_archive_extract(ctx.h if ctx is not None else None, archive, len(archive), mode, C.byref(rc))
     try:
-        if rc.value != 0:
-            raise B.ZpqError(rc.value, "archive_extract")
+        if rc.value != 0 or not h:
+            raise B.ZpqError(rc.value or -9, "archive_extract")
         out = []
         for i in range(L.zpqf_archive_nfiles(h)):
             size = L.zpqf_archive_size(h, i)
