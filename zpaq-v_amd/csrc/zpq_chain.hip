@@ -176,7 +176,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
 #ifdef ZPQ_NO_HYP
     constexpr bool HYP = false;
 #else
-    constexpr bool HYP = DEC && !SPEC && !SP && !MIXT && (NCH == 2 || NCH == 3) && GG == 8;
+    // Round 4: the chain of five (level 3) as well, at SIXTEEN lanes per block -- ten of them the two copies of its five
+    // components -- and with the line store: 16 blocks per CU are then four waves, one per SIMD, where the eight-lane
+    // decoder left two SIMDs without a wave.  With the store only the copy that guessed the nibble's
+    // last bit right probes, claims and reloads (take_prefetched); the other takes over its result.
+    constexpr bool HYP16 = DEC && !SPEC && !MIXT && NCH == 5 && GG == 16;
+    constexpr bool HYP = (DEC && !SPEC && !SP && !MIXT && (NCH == 2 || NCH == 3) && GG == 8) || HYP16;
 #endif
     // The other decoders (longer chains, MIX2, line store) have no lanes to spare for a second copy.  They request the
     // next nibble's rows for BOTH outcomes of the nibble's last bit as soon as its third bit is known -- a whole bit step
@@ -388,6 +393,13 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 v = __builtin_amdgcn_update_dpp(v, v, 0x44 /*quad_perm:[0,1,0,1]*/, 0xf, 0xa, false);
                 return __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
             }
+            if constexpr (HYP && NCH == 5) {
+                // the coder lanes are 8 and 9 of the block's sixteen (both hold the bit): over their quad, then to the two
+                // quads below (the lanes above work for no component)
+                v = __builtin_amdgcn_update_dpp(v, v, 0x44 /*quad_perm:[0,1,0,1]*/, 0xf, 0x4, false);
+                v = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x2, false);
+                return __builtin_amdgcn_update_dpp(v, v, 0x108 /*row_shl:8*/, 0xf, 0x1, false);
+            }
             if constexpr (NCH > 0 && NCH + (MIXT ? 1 : 0) <= 4) {
                 // all of the block's lanes are in one quad: one quad_perm broadcast of the coder lane
                 constexpr int L = NCH + (MIXT ? 1 : 0) - 1;
@@ -533,6 +545,10 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
                 sel_alt = false;
             }
+            // two hypotheses over a line store: the copy whose request was for the nibble that really follows resolves it (walk,
+            // claim, reload); the other copy's request was for a context that never came -- it claims nothing (a claim there
+            // would fill the store with lines no context owns) and takes the result over below
+            const bool sp_act = !HYP || row_mine;
             if (SPARSE && sp_cap) {
                 const u32 o = n_si & 3u;
                 // slots of a group that end the probe -- the line's own tag, or a free slot -- as a 4-bit mask rotated
@@ -545,7 +561,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 u32x4 T = n_tags;
                 u32 g = n_si >> 2;
                 u32 r = probe_group(T);
-                if (r == 0u && !sp_full) {                                     // home group full of other lines: walk on
+                if (r == 0u && !sp_full && sp_act) {                           // home group full of other lines: walk on
                     for (u32 tries = 1; tries < sp_groups; tries++) {
                         g = (g + 1u == sp_groups) ? 0u : g + 1u;
                         T = *reinterpret_cast<const u32x4 *>(sp_tags + 4u * g);
@@ -556,7 +572,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const u32 idx = (o + (u32)__builtin_ctz(r | 16u)) & 3u;
                 const u32 t = (idx & 2u) ? ((idx & 1u) ? T.w : T.z) : ((idx & 1u) ? T.y : T.x);
                 const u32 si = 4u * g + idx;
-                if (r == 0u) { status = ZPQ_E_TOOBIG; sp_full = true; }        // every slot taken: the block is larger than promised
+                if (!sp_act) { }                                               // (wrong copy: nothing to resolve)
+                else if (r == 0u) { status = ZPQ_E_TOOBIG; sp_full = true; }   // every slot taken: the block is larger than promised
                 else if (t == 0u && ++sp_claims > sp_limit) { status = ZPQ_E_TOOBIG; sp_full = true; }   // (nearly) full: stop before probes get long
                 else if (t == 0u) {
                     // claim: the line becomes this context's and starts out all zero, like an untouched dense line.
@@ -597,6 +614,13 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 X.r0 = row_mine ? X.r0 : x0; X.r1 = row_mine ? X.r1 : x1; X.r2 = row_mine ? X.r2 : x2; X.r3 = row_mine ? X.r3 : x3;
                 roff = row_mine ? roff : xo;
                 if (TOUCHC) { const u32 xt = xchg(tw_line); tw_line = row_mine ? tw_line : xt; }
+                if constexpr (SPARSE) {
+                    // the store's bookkeeping lives on both copies and must agree: what the resolving copy counted and found
+                    const u32 xc = xchg(sp_claims), xs = xchg((u32)status), xf = xchg(sp_full ? 1u : 0u);
+                    sp_claims = row_mine ? sp_claims : xc;
+                    status = row_mine ? status : (i32)xs;
+                    sp_full = row_mine ? sp_full : (xf != 0u);
+                }
             }
             // keep the stores BELOW the wait for the loads above (vmcnt is in-order: a store issued
             // first would be waited for as well)
@@ -1433,6 +1457,14 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     if (!build_cfg(hostM, &cfg)) return ZPQ_E_INTERNAL;
     const bool hio = B->gate_flag != nullptr || B->prog_counter != nullptr;
     if (hio && !zpq_chain_has_hio(hostM)) return ZPQ_E_INTERNAL;
+    // The DECODER of the chain of five (level 3) gives a block sixteen lanes, two copies of every component (HYP16 in k_chain);
+    // ZPQ_DEC_HYP16=0 keeps the eight-lane decoder (tests and A/B runs compare the two).
+    bool hyp16 = false;
+    if (decode && cfg.nch_spec == 5 && !cfg.has_mix2 && cfg.g == 8 && blocks_per_wg % 4 == 0) {
+        const char *ev = getenv("ZPQ_DEC_HYP16");
+        hyp16 = !(ev && atoi(ev) == 0);
+    }
+    if (hyp16) cfg.g = 16;
     if (blocks_per_wg < 64 / cfg.g || blocks_per_wg > cfg.blocks_per_wg || blocks_per_wg % (64 / cfg.g)) return ZPQ_E_INTERNAL;
     if (name_out) *name_out = decode ? "k_chain<decode>" : "k_chain<encode>";
     if (!decode && zpq_pipe_applies(hostM, blocks_per_wg, B->nslots)) {
@@ -1470,7 +1502,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
         switch (cfg.nch_spec) {                                                                          \
         case 2: ZPQ_LAUNCH_SP(D, 2, 8); break;          /* level 1 */                                    \
         case 3: ZPQ_LAUNCH_SP(D, 3, 8); break;          /* level 2 */                                    \
-        case 5: ZPQ_LAUNCH_SP(D, 5, 8); break;          /* level 3 */                                    \
+        case 5: if ((D) && hyp16) ZPQ_LAUNCH_SP(D, 5, ((D) ? 16 : 8)); else ZPQ_LAUNCH_SP(D, 5, 8); break;   /* level 3 */ \
         case 6: ZPQ_LAUNCH(D, 6, true, 8, true); break;       /* level 4 */                              \
         case 8: ZPQ_LAUNCH(D, 8, true, 16, true); break;      /* level 5 */                              \
         default:                                                                                         \
