@@ -19,7 +19,7 @@ from test_gpu_chain import mixed_blocks  # noqa: E402
 from test_gpu_pipe import small_table_header  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-LEVELS = [3]
+LEVELS = [3, 4]
 
 
 def decode_both(zpq, gpu_ctx, monkeypatch, model, coded, cap, flags=None):
@@ -63,7 +63,7 @@ def test_inverts_the_oracles_streams(zpq, gpu_ctx, monkeypatch, level, store):
             assert (first == 0).all()
 
 
-@pytest.mark.parametrize("level,bits", [(3, 0), (3, 1), (3, 2), (3, 4)])
+@pytest.mark.parametrize("level,bits", [(3, 0), (3, 1), (3, 2), (3, 4), (4, 0), (4, 1), (4, 3)])
 def test_rows_under_heavy_aliasing(zpq, gpu_ctx, monkeypatch, level, bits):
     """Every hash table shrunk to 64 << bits bytes: the row being finished is, all the time, one of the three candidates
     of the request in flight, for one copy's outcome of the bit or for both."""
@@ -140,8 +140,9 @@ def test_64k_blocks_all_classes_both_table_forms(zpq, gpu_ctx, monkeypatch, leve
     """Sixty-four 64 KiB blocks of the bench generator's four classes, dense tables and the line store sized as bench.py's
     ctx sizes it (1.12 x the touched-line bound), against the oracle's streams."""
     model = zpq.Model(level=level)
-    arr = W.make_blocks(64, 65536)
-    blocks = [arr[i].tobytes() for i in range(64)]
+    nb = 64 if level == 3 else 32                                   # (level 4 dense: 385 MiB of tables per block)
+    arr = W.make_blocks(nb, 65536)
+    blocks = [arr[i].tobytes() for i in range(nb)]
     coded = O.encode_blocks(model.header, blocks, nthreads=min(16, os.cpu_count() or 1), slack=80000)
     for mode in ("never", "always"):
         monkeypatch.setenv("ZPQ_SPARSE_MODE", mode)
@@ -149,3 +150,25 @@ def test_64k_blocks_all_classes_both_table_forms(zpq, gpu_ctx, monkeypatch, leve
         assert bool(gpu_ctx.last_line_store) == (mode == "always")
         assert (status == 0).all() and dec == blocks and (first == 0).all()
         assert [int(c) for c in consumed] == [len(c) for c in coded]
+
+
+def test_mix2_weights_alias_between_nibbles(zpq, gpu_ctx, monkeypatch):
+    """Level 4 with its MIX2 weight table shrunk to 256 entries: a candidate weight of the next nibble is all the time an
+    entry the nibble that just ended trained under another lane (forwarded from LDS), for both copies' training."""
+    h = bytearray(O.level_header(4))
+    sz = [0, 2, 3, 2, 3, 4, 6, 6, 3, 5]
+    p = 5
+    for _ in range(h[4]):
+        if h[p] == 6:
+            h[p + 1] = 8
+        p += sz[h[p]]
+    header = bytes(h)
+    model = zpq.Model(header=header)
+    assert model.has_fast_path
+    rnd = random.Random(4004)
+    blocks = mixed_blocks(rnd, 30, [0, 1, 17, 300, 1000, 3000, 5000])
+    coded = O.encode_blocks(header, blocks, nthreads=4)
+    for mode in ("never", "always"):
+        monkeypatch.setenv("ZPQ_SPARSE_MODE", mode)
+        dec, status, *_ = decode_both(zpq, gpu_ctx, monkeypatch, model, coded, 5100)
+        assert (status == 0).all() and dec == blocks

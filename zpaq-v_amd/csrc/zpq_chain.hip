@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // components -- and with the line store: 16 blocks per CU are then four waves, one per SIMD, where the eight-lane
     // decoder left two SIMDs without a wave.  With the store only the copy that guessed the nibble's
     // last bit right probes, claims and reloads (take_prefetched); the other takes over its result.
-    constexpr bool HYP16 = DEC && !SPEC && !MIXT && NCH == 5 && GG == 16;
+    // ... and the chain of six with its MIX2 (level 4): fourteen lanes, the MIX2's two copies on lanes 12 and 13.
+    constexpr bool HYP16 = DEC && !SPEC && GG == 16 && ((!MIXT && NCH == 5) || (MIXT && NCH == 6));
     constexpr bool HYP = (DEC && !SPEC && !SP && !MIXT && (NCH == 2 || NCH == 3) && GG == 8) || HYP16;
 #endif
     // The other decoders (longer chains, MIX2, line store) have no lanes to spare for a second copy.  They request the
@@ -399,6 +400,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 v = __builtin_amdgcn_update_dpp(v, v, 0x44 /*quad_perm:[0,1,0,1]*/, 0xf, 0x4, false);
                 v = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x2, false);
                 return __builtin_amdgcn_update_dpp(v, v, 0x108 /*row_shl:8*/, 0xf, 0x1, false);
+            }
+            if constexpr (HYP && NCH == 6) {
+                // MIX2 = component 6: the coder lanes are 12 and 13 of the row; over their quad (lanes 14, 15 follow the bits
+                // too: they help fetch the MIX2's candidate weights), then to the three quads below
+                v = __builtin_amdgcn_update_dpp(v, v, 0x44 /*quad_perm:[0,1,0,1]*/, 0xf, 0x8, false);
+                const i32 a = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x4, false);
+                const i32 b = __builtin_amdgcn_update_dpp(a, a, 0x108 /*row_shl:8*/, 0xf, 0x3, false);
+                return b;
             }
             if constexpr (NCH > 0 && NCH + (MIXT ? 1 : 0) <= 4) {
                 // all of the block's lanes are in one quad: one quad_perm broadcast of the coder lane
@@ -648,6 +657,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // ZPAQL.run(byte) + h[] copy (predictor.v:809-816) -> this lane's next context hash
         // vm_hash: the contexts a byte leads to, WITHOUT touching the VM's state (the two-hypothesis decoder asks for a
         // byte that may not be the one decoded); vm_commit: the state change once the byte is certain.
+        u32 vm_last = 0;                                   // (set by vm_hash) the LAST component's context hash for that byte: the MIX2's
         auto vm_hash = [&](const u32 byte) -> u32 {
             u32 hv = 0;
             // the specialised kernels are only launched for their level's own program shape (chain of 2 = level 1's
@@ -657,6 +667,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 // b=c c-- *c=a d=0 (hash *d=a d++)* hash *d=a halt: H[k] = hash^(k+1) of (byte, prev)
                 u32 a = byte;
                 for (int k = 0; k < n; k++) { a = (a + prev + 512u) * 773u; hv = (k == lc) ? a : hv; }
+                vm_last = a;
             } else if (vm_kind == VM_LEVEL1) {
                 // *b=a a=0 d=0 hash b-- hash *d=a d++ b-- hash b-- hash *d=a halt, M = 4 bytes
                 const u32 mm = (m4 & ~(255u << ((b4 & 3) * 8))) | (byte << ((b4 & 3) * 8));
@@ -797,6 +808,62 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const u32 sl = (u32)li + (u32)q * GG;
                 if (sl >= 1u && sl <= 15u) w16s[sl] = (u16)(mwhit[q] ? mwf[q] : mwl[q]);
             }
+        };
+
+        // Two-hypothesis decoder with a MIX2 (level 4, HYP16): the candidates are asked for PER HYPOTHESIS, a bit step early, like
+        // the rows.  When three bits of a nibble are known each copy derives the next nibble's prefix under ITS outcome of the
+        // fourth bit and its eight lanes fetch the fifteen candidates (lane pair q: slots q and q + 8).  When the bit is known
+        // (mixs_arrive, behind take_prefetched) copy 0 writes the ended nibble's candidates back, the copy that was right
+        // parks its loaded values in LDS -- an entry that was also a candidate of the nibble that just ended is taken from
+        // LDS, where its trained value sits (its load went out before that nibble's last training and write-back) -- and both
+        // copies adopt its addresses.  ZPQ_MIXW_SPEC=0 at build time: ask after the bit, as the one-copy decoders do.
+#ifndef ZPQ_MIXW_SPEC
+#define ZPQ_MIXW_SPEC 1
+#endif
+        constexpr bool MIXS = HYP && MIXT && (ZPQ_MIXW_SPEC != 0);
+        u32 ms_cur[2] = {0, 0}, ms_new[2] = {0, 0}, ms_ld[2] = {0, 0};
+        u32 ms_hm = 0, ms_prefix = 1;                      // what THIS copy's request in flight was derived from
+        u32 hctx_mix = 0, hn_spec_mix = 0, hnext_mix = 0;  // the MIX2's context hash: this byte / next byte under this copy's outcome / next byte
+        auto mixs_request = [&](const u32 hm, const u32 prefix) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 sl = (u32)(li >> 1) + 8u * (u32)q;
+                const u32 slv = max(sl, 1u);                 // (slot 0 does not exist: lane pair 0 re-reads slot 1, unused)
+                const u32 L = 31u - (u32)__clz((int)slv);
+                const u32 c8c = (prefix << L) | (slv - (1u << L));
+                const u32 na = (hm + (c8c & mix_mask)) & mix_cmask;
+                ms_new[q] = na;
+                ms_ld[q] = a16m[na];
+            }
+            ms_hm = hm;
+            ms_prefix = prefix;
+        };
+        auto mixs_arrive = [&]() {
+            const u32 plen_old = 32u - (u32)__clz((int)mix_prefix);
+            u32 fwd[2];
+            bool hit[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 sl = (u32)(li >> 1) + 8u * (u32)q;
+                if (mix_live && hyp == 0 && sl >= 1u) a16m[ms_cur[q]] = w16s[sl];     // the nibble that ended: values are final
+                const u32 d = (ms_new[q] - mix_hm) & mix_cmask;
+                const u32 dlen = 32u - (u32)__clz((int)(d | 1u));
+                const u32 Lo = dlen - plen_old;
+                hit[q] = mix_live && d != 0u && d <= 255u && dlen >= plen_old && Lo <= 3u && (d >> Lo) == mix_prefix;
+                const u32 so = (1u << (Lo & 3u)) | (d & ((1u << (Lo & 3u)) - 1u));
+                fwd[q] = w16s[hit[q] ? so : 0u];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 sl = (u32)(li >> 1) + 8u * (u32)q;
+                if (row_mine && sl >= 1u) w16s[sl] = (u16)(hit[q] ? fwd[q] : ms_ld[q]);
+                const u32 xa = xchg(ms_new[q]);
+                ms_cur[q] = row_mine ? ms_new[q] : xa;
+            }
+            const u32 xh = xchg(ms_hm), xp = xchg(ms_prefix);
+            mix_hm = row_mine ? ms_hm : xh;
+            mix_prefix = row_mine ? ms_prefix : xp;
+            mix_live = true;
         };
 
 #ifdef ZPQ_NO_SKEW
@@ -1035,6 +1102,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 pin = me ? pv : pin;
                 p = me ? pn : p;
             }
+            i32 pj = 0, pk = 0, wmix = 0;
+            if constexpr (MIXT) {
+                // the MIX2 mixes p[NCH - 2] and p[NCH - 1] (checked on the host) of ITS copy: the lanes four and two below
+                pk = __builtin_amdgcn_update_dpp(p, p, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+                pj = __builtin_amdgcn_update_dpp(p, p, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+                wmix = (i32)w16s[X.slot];                     // the nibble's candidate weights live in LDS (mixw_request)
+                const i32 pm = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                p = is_last ? pm : p;
+            }
             const i32 sq = s_squash[p + 2048];
             // ---- this copy's outcome
             const i32 yh = hyp;
@@ -1079,6 +1155,24 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             // ---- commit / take over
             const bool mine = y == yh;
             if (mine) { t32[s] = nv; t8[s] = (u8)nb; }          // one copy trains the (shared) table entry
+            if constexpr (MIXT) {
+                // MIX2 weight (predictor.v:744-762), trained by the copy that was right
+                const i32 em = wmul(err, mix_rate) >> 5;
+                i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                w = min(max(w, 0), 65535);
+                if (mine && ctype == ZT_MIX2) w16s[X.slot] = (u16)w;
+                if (K == 3 && !MIXS) {
+                    // this nibble's weights are final: write the candidates back and request the next nibble's (all sixteen
+                    // lanes of the row, after the bit: hash and prefix from the coder lane, as in bitstep)
+                    const u32 c8n2 = (u32)row_bcast((i32)((X.c8 << 1) | (u32)y), row_base + comp_lane(last));
+                    if (bit == 4) mixw_request((u32)row_bcast((i32)hctx, row_base + comp_lane(last)), c8n2);
+                    else {
+                        const u32 xh2 = xchg(hn_spec);
+                        const u32 hn_true = mine ? hn_spec : xh2;
+                        mixw_request((u32)row_bcast((i32)hn_true, row_base + comp_lane(last)), 1u);
+                    }
+                }
+            }
             if (K < 3) {
                 const u32 xv = xchg(nxt_v), xb = xchg(nxt_bs);
                 cur_v = mine ? nxt_v : xv;
@@ -1092,6 +1186,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 if (bit == 0) {
                     const u32 xh = xchg(hn_spec);
                     hnext_dec = mine ? hn_spec : xh;
+                    if (MIXS) { const u32 xm = xchg(hn_spec_mix); hnext_mix = mine ? hn_spec_mix : xm; }
                     vm_commit(((X.c8 << 1) | (u32)y) - 256u);
                 }
             }
@@ -1118,8 +1213,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 // the fourth.  The request has the whole last bit step (~1000 cycles) to travel before it is needed;
                 // the HBM round trip measured here is ~1350 cycles.
                 const u32 c8n = (X.c8 << 1) | (u32)hyp;
-                if (bit == 5) prefetch_rows(hctx, c8n);
-                else { hn_spec = vm_hash(c8n - 256u); prefetch_rows(hn_spec, 1u); }
+                if (bit == 5) { prefetch_rows(hctx, c8n); if (MIXS) mixs_request(hctx_mix, c8n); }
+                else {
+                    hn_spec = vm_hash(c8n - 256u);
+                    prefetch_rows(hn_spec, 1u);
+                    if (MIXS) { hn_spec_mix = vm_last; mixs_request(hn_spec_mix, 1u); }
+                }
                 // (Asking one bit earlier still -- both outcomes of the last bit under this copy's outcome of the third,
                 //  four lines per nibble and table -- was measured: 320.7 vs 266.6 ms.  The memory system is loaded
                 //  enough that doubling the row reads costs more latency than the earlier request hides.)
@@ -1132,7 +1231,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // nibble start: find_ht (predictor.v:495-532); three rows of one 64-byte line
 
         prefetch_rows(0u, 1u);                             // first nibble of the first byte: h = 0, c8 = 1
-        if (DEC && mixreg) mixw_request(0u, 1u);
+        if (DEC && mixreg) { if (MIXS) mixs_request(0u, 1u); else mixw_request(0u, 1u); }
         // Encode, specialised kernels: the prediction chain as a PIPELINE over bytes.  Every context, bit and
         // bit-history state of the encoder is a function of the input alone; only predictions flow down the chain.
         // So in iteration `it` lane c works on byte it - c: the ICM is one byte ahead of the first ISSE, which is one
@@ -1192,7 +1291,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             take_prefetched(bi != 0, std::false_type{});      // rows of this byte's first nibble
             if (DEC && pend_store) { dst[pend_pos] = (u8)pend_val; pend_store = false; }   // (see pend_store)
             if (!DEC && is_last) oq_flush();
-            if (DEC && mixreg) mixw_arrive();
+            if (DEC && mixreg) { if (MIXS) mixs_arrive(); else mixw_arrive(); }
             if (!DEC && mixreg) mix_byte_begin(ch, bi != 0);  // (before the prefetch below, see mix_byte_begin)
             if (!DEC) {
                 hnext = run_vm(ch);                           // contexts of the NEXT byte: known now
@@ -1204,7 +1303,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             step(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
             step(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});     // decode: requests the next rows inside
             take_prefetched(true, std::true_type{});
-            if (DEC && mixreg) mixw_arrive();
+            if (DEC && mixreg) { if (MIXS) mixs_arrive(); else mixw_arrive(); }
             if (!DEC) prefetch_rows(hnext, 1u);               // first nibble of the next byte
             nibble_begin();
             step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -1213,6 +1312,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             step(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
             const u32 byte = X.c8 - 256;
             hctx = DEC ? hnext_dec : hnext;
+            if (MIXS) hctx_mix = hnext_mix;
 
             if (DEC) {
                 if ((B.flags & ZPQ_FLAG_PP) && !got_first) { first = byte; got_first = true; }
@@ -1460,7 +1560,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     // The DECODER of the chain of five (level 3) gives a block sixteen lanes, two copies of every component (HYP16 in k_chain);
     // ZPQ_DEC_HYP16=0 keeps the eight-lane decoder (tests and A/B runs compare the two).
     bool hyp16 = false;
-    if (decode && cfg.nch_spec == 5 && !cfg.has_mix2 && cfg.g == 8 && blocks_per_wg % 4 == 0) {
+    if (decode && ((cfg.nch_spec == 5 && !cfg.has_mix2) || (cfg.nch_spec == 6 && cfg.has_mix2)) && cfg.g == 8 && blocks_per_wg % 4 == 0) {
         const char *ev = getenv("ZPQ_DEC_HYP16");
         hyp16 = !(ev && atoi(ev) == 0);
     }
@@ -1503,7 +1603,7 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
         case 2: ZPQ_LAUNCH_SP(D, 2, 8); break;          /* level 1 */                                    \
         case 3: ZPQ_LAUNCH_SP(D, 3, 8); break;          /* level 2 */                                    \
         case 5: if ((D) && hyp16) ZPQ_LAUNCH_SP(D, 5, ((D) ? 16 : 8)); else ZPQ_LAUNCH_SP(D, 5, 8); break;   /* level 3 */ \
-        case 6: ZPQ_LAUNCH(D, 6, true, 8, true); break;       /* level 4 */                              \
+        case 6: if ((D) && hyp16) ZPQ_LAUNCH(D, 6, true, ((D) ? 16 : 8), true); else ZPQ_LAUNCH(D, 6, true, 8, true); break;   /* level 4 */ \
         case 8: ZPQ_LAUNCH(D, 8, true, 16, true); break;      /* level 5 */                              \
         default:                                                                                         \
             if (cfg.g == 8) ZPQ_LAUNCH(D, 0, false, 8, true); else ZPQ_LAUNCH(D, 0, false, 16, true);    \
