@@ -104,7 +104,7 @@ def source_ranges(src_path):
         marks.sort()
 
     def role_of(line):
-        r = "setup / other"
+        r = "line 0 (optimiser-merged code, exec-mask save/restore, mask algebra)"
         for ln, role in marks:
             if ln <= line:
                 r = role
