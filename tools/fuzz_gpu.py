@@ -26,6 +26,7 @@ ap.add_argument("--only", type=int, default=-1, help="run only batch number N of
 ap.add_argument("--general", action="store_true", help="general models: random mixes of the nine component types (inputs = earlier "
                 "components, hash-chain program), C4b, levels 2-3 as general models -- the wave-per-component encoder k_gpipe in its "
                 "byte-batched and bit-serial forms, decoded back by k_rows")
+ap.add_argument("--levels", default="", help="comma-separated levels to draw from instead of the default mix (e.g. 3,4: the round-4 decoders)")
 a = ap.parse_args()
 
 z = ge.load()
@@ -101,6 +102,8 @@ while time.time() < t_end:
             break
         continue
     which = r.choice([1, 1, 2, 2, 2, 3, 3, 4, 5, "c4b"])
+    if a.levels:
+        which = r.choice([int(x) for x in a.levels.split(",")])
     lanes_flag = 0
     if a.general:
         which = r.choice(["rnd", "rnd", "rnd", "c4b", "c4b", 2, 3])
@@ -124,10 +127,12 @@ while time.time() < t_end:
         blocks = [make(r.randrange(6), r.randint(0, maxlen) if r.random() < 0.8 else maxlen, r) for _ in range(nb)]
         if r.random() < 0.3:
             env["ZPQ_GPIPE_BATCH"] = "0"
-    if which in (1, 2, 3) and r.random() < 0.3:
+    if which in (1, 2, 3, 4) and r.random() < 0.3:
         env["ZPQ_SPARSE_FORCE_LOG2"] = str(r.choice([12, 13, 15]))
-    elif which in (1, 2, 3) and r.random() < 0.3:
+    elif which in (1, 2, 3, 4) and r.random() < 0.3:
         env["ZPQ_SPARSE_MODE"] = r.choice(["never", "always"])
+    if which in (3, 4) and r.random() < 0.15:
+        env["ZPQ_DEC_HYP16"] = "0"                          # (the eight-lane decoders stay covered)
     if which in (1, 2, 3) and r.random() < 0.15:
         env["ZPQ_ENC_PIPE"] = "0"
     budget = None

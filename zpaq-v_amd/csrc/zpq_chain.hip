@@ -1085,6 +1085,48 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // (next state and its entry, the counter's next value and its stretch, the next nibble's rows); then the
         // squash-dependent training; then the coder; then commit / take-over.
         u32 hn_spec = 0;                                   // next byte's context hash under this copy's outcome of the last bit
+        // The prediction chain of ONE bit from every lane's table entry (v, b): p0 -> p1 -> ... (-> MIX2), each copy among its
+        // own lanes.  Returns this lane's prediction, its input, and (MIX2) what its training needs.
+        struct Pred { i32 p, pin, pj, pk, wmix; };
+        auto chain_of = [&](const u32 v, const i32 b, const u32 mslot) -> Pred {
+            const i32 w0c = ((i32)(v << 12)) >> 12;
+            const i32 w1c = (i32)(((u32)b << 12) | (v >> 20));
+            Pred R;
+            R.p = is_icm ? icm_st(v, b) : 0; R.pin = 0; R.pj = 0; R.pk = 0; R.wmix = 0;
+#pragma unroll
+            for (int i = 1; i < (NCH ? NCH : 1); i++) {
+                const i32 pv = __builtin_amdgcn_update_dpp(R.p, R.p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, false);
+                const i32 pn = clamp2k((__mul24(w0c, pv) + (w1c << 6)) >> 16);
+                const bool me = lc == i;
+                R.pin = me ? pv : R.pin;
+                R.p = me ? pn : R.p;
+            }
+            if constexpr (MIXT) {
+                // the MIX2 mixes p[NCH - 2] and p[NCH - 1] (checked on the host) of ITS copy: the lanes four and two below
+                R.pk = __builtin_amdgcn_update_dpp(R.p, R.p, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+                R.pj = __builtin_amdgcn_update_dpp(R.p, R.p, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+                R.wmix = (i32)w16s[mslot];                    // the nibble's candidate weights live in LDS (mixw_request / mixs_arrive)
+                const i32 pm = clamp2k(wadd(wmul(R.wmix, R.pj), wmul(65536 - R.wmix, R.pk)) >> 16);
+                R.p = is_last ? pm : R.p;
+            }
+            return R;
+        };
+        // AHEAD (round 4): inside a nibble each copy also runs the NEXT bit's chain and squash lookup for its outcome of this
+        // bit -- its next state's entry with its own training forwarded is all the chain needs -- BEFORE the coder resolves
+        // this bit.  The copy that was right hands (input, squash, MIX2 operands) over with the entry, and the next step starts
+        // at its coder: the chain's DPP hops and the squash's LDS round trip leave the bit-to-bit critical path (they were
+        // ~200 cycles of the ~340 a bit step spends waiting).  The first bit of a nibble has a new row and predicts as before.
+        // MEASURED SLOWER on every level (same box, alternating runs, profiles/r04_ahead_ab.txt): level 2 x 8192 272-274 against
+        // 257.7-257.9 ms, level 1 282 against 261, level 3 360 against 337, level 4 484 against 455-459.  The bit step's one LDS
+        // round trip does not go away -- the next state's entry and the ICM's stretch of its trained counter (needed when the state
+        // repeats) must have arrived before the early chain can start, where they used to arrive behind the coder -- and the
+        // hand-over grows by two to five registers.  Parity-green (the whole GPU suite ran on it).  Compiled only with -DZPQ_AHEAD.
+#ifdef ZPQ_AHEAD
+        constexpr bool AHEAD = HYP;
+#else
+        constexpr bool AHEAD = false;
+#endif
+        i32 a_pin = 0, a_sq = 0, a_pj = 0, a_pk = 0, a_wmix = 0;
         auto bitstep_hyp = [&](auto kc, auto nbc) {
             constexpr int K = decltype(kc)::value;
             constexpr int bit = (decltype(nbc)::value ? 3 : 7) - K;
@@ -1093,25 +1135,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const u32 cmv = cur_v & 0x7FFFFFu;
             const i32 w0 = ((i32)(cur_v << 12)) >> 12;
             const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
-            i32 p = is_icm ? cur_pst : 0, pin = 0;
-#pragma unroll
-            for (int i = 1; i < (NCH ? NCH : 1); i++) {
-                const i32 pv = __builtin_amdgcn_update_dpp(p, p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, false);
-                const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);
-                const bool me = lc == i;
-                pin = me ? pv : pin;
-                p = me ? pn : p;
+            i32 pin, pj, pk, wmix, sq;
+            if constexpr (AHEAD && K > 0) {
+                pin = a_pin; pj = a_pj; pk = a_pk; wmix = a_wmix; sq = a_sq;     // predicted during the previous bit
+            } else {
+                const Pred P = chain_of(cur_v, cur_b, X.slot);
+                pin = P.pin; pj = P.pj; pk = P.pk; wmix = P.wmix;
+                sq = s_squash[P.p + 2048];
             }
-            i32 pj = 0, pk = 0, wmix = 0;
-            if constexpr (MIXT) {
-                // the MIX2 mixes p[NCH - 2] and p[NCH - 1] (checked on the host) of ITS copy: the lanes four and two below
-                pk = __builtin_amdgcn_update_dpp(p, p, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
-                pj = __builtin_amdgcn_update_dpp(p, p, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
-                wmix = (i32)w16s[X.slot];                     // the nibble's candidate weights live in LDS (mixw_request)
-                const i32 pm = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
-                p = is_last ? pm : p;
-            }
-            const i32 sq = s_squash[p + 2048];
             // ---- this copy's outcome
             const i32 yh = hyp;
             u32 sN = 0, rNv = 0;
@@ -1137,6 +1168,13 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const bool same = sN == s;
                 nxt_v = same ? nv : rNv;
                 nxt_bs = ((u32)(same ? nb : rNb) & 255u) | (sN << 8);
+            }
+            // ---- the next bit's chain under this copy's outcome (see AHEAD)
+            Pred Q = {0, 0, 0, 0, 0};
+            i32 sq2 = 0;
+            if constexpr (AHEAD && K < 3) {
+                Q = chain_of(nxt_v, (i32)(int8_t)(nxt_bs & 255u), X.slot * 2u + (u32)yh);
+                sq2 = s_squash[Q.p + 2048];
             }
             // ---- the bit (both copies decode it: same code, same window, same bounds)
             i32 y = 0;
@@ -1180,6 +1218,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 cur_b = (i32)(int8_t)(bs & 255u);
                 cur_s = bs >> 8;
                 cur_pst = icm_st(cur_v, cur_b);
+                if constexpr (AHEAD) {
+                    const i32 xq = (i32)xchg((u32)sq2), xi = (i32)xchg((u32)Q.pin);
+                    a_sq = mine ? sq2 : xq;
+                    a_pin = mine ? Q.pin : xi;
+                    if constexpr (MIXT) {
+                        const i32 xj = (i32)xchg((u32)Q.pj), xk = (i32)xchg((u32)Q.pk), xw = (i32)xchg((u32)Q.wmix);
+                        a_pj = mine ? Q.pj : xj; a_pk = mine ? Q.pk : xk; a_wmix = mine ? Q.wmix : xw;
+                    }
+                }
             } else {
                 if (HYP4 && bit == 4) sel_alt = y != 0;         // (the copy whose third bit was right holds both outcomes of this one)
                 else row_mine = mine;
