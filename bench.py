@@ -299,6 +299,10 @@ def main():
         if a.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
+            # one node: the ranks meet over the loopback interface (gloo would otherwise resolve the container's host name, which
+            # need not resolve on these boxes)
+            if os.path.isdir("/sys/class/net/lo"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(backend=a.backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)

@@ -22,7 +22,7 @@ def decode_both(zpq, gpu_ctx, monkeypatch, model, coded, cap, flags=None):
     """Decode with both decoders; everything the ABI returns must agree (a refused block's bytes are unspecified)."""
     kw = {} if flags is None else {"flags": flags}
     assert len(coded) >= 12                      # (smaller batches stay with the lane-per-component decoder)
-    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")      # (opt-in: the lane-per-component decoder measured faster, DESIGN.md 4.5)
+    monkeypatch.setenv("ZPQ_DEC_PIPE", "1")      # (opt-in: the lane-per-component decoder measured faster, EXPERIMENTS.md 4.5)
     a = gpu_ctx.decode_blocks(model, coded, cap=cap, **kw)
     assert gpu_ctx.last_kernel_name == "k_dpipe<decode>"
     monkeypatch.delenv("ZPQ_DEC_PIPE", raising=False)

@@ -127,7 +127,7 @@ def test_output_overflow_is_reported_not_written(zpq, gpu_ctx, monkeypatch):
 
 
 def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
-    """A component wave with only a few active lanes runs at half speed: fewer than 12 resident blocks
+    """A component wave with only a few active lanes runs at half speed (EXPERIMENTS.md 4.4): fewer than 12 resident blocks
     are coded by zpq_chain.hip's encoder; 12 and more by the pipeline, regrouped evenly over its workgroups."""
     model = zpq.Model(level=2)
     for n, name in ((1, "k_chain<encode>"), (11, "k_chain<encode>"), (12, "k_pipe<encode>"), (37, "k_pipe<encode>")):

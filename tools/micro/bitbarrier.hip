@@ -1,4 +1,4 @@
-// Micro-benchmark for a wave-split DECODER: what does one hand-off per coded bit cost when it is
+// Micro-benchmark for a wave-split DECODER (EXPERIMENTS.md 4.5): what does one hand-off per coded bit cost when it is
 // an LDS mailbox + s_barrier instead of a spin (tools/micro/pingpong.hip: ~210 cycles per hop)?
 // NW waves of one workgroup; per iteration every wave
 //   reads the other waves' mailbox words of the previous iteration (one ds_read per producer),

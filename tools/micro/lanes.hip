@@ -1,5 +1,5 @@
 // Micro-benchmark: does the speed of a lone wave depend on HOW MANY of its lanes are active?
-// (k_pipe's component waves ran at half speed with <= 8 active lanes)
+// (k_pipe's component waves ran at half speed with <= 8 active lanes, EXPERIMENTS.md 4.4.)
 // One workgroup of 4 waves (one per SIMD).  Modes 0-2: lanes >= N are switched off for the whole loop (a dependent
 // VALU chain, dependent LDS reads, four independent VALU chains).  Mode 3: every iteration runs 96 VALU instructions
 // on all 64 lanes and then 32 on the first N lanes only -- the shape of a coder section inside a full-width bit step.

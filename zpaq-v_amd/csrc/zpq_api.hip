@@ -445,7 +445,7 @@ static int plan_batch(zpq_ctx *c, const zpq_model *m, uint32_t flags, int nblock
             nslots = dn; grid = dg; bpw = db;
             // Dense tables WITHOUT clearing (12 MiB per level-2 block), one "touched" bit per row instead: built for the
             // wave-pipelined encoder and the two-hypothesis decoder, parity-green, measured slower than the clearing it saves
-            //  -- only the -DZPP_TOUCH / -DZPQ_TOUCH_DEC timing builds take this path (ZPQ_TOUCH=0: not even they).
+            // (EXPERIMENTS.md 4.1) -- only the -DZPP_TOUCH / -DZPQ_TOUCH_DEC timing builds take this path (ZPQ_TOUCH=0: not even they).
             const char *tv = getenv("ZPQ_TOUCH");
             int tn = 0, tg = 0, tb = 0;
             const bool kernel_ok = decode ? zpq_chain_touch_decode(&m->d) != 0 : (zpq_pipe_touch() && zpq_pipe_applies(&m->d, db, dn) != 0);

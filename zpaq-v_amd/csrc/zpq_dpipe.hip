@@ -678,7 +678,7 @@ static bool dpipe_layout(const Cfg &cfg, int bpw, zpqd::DLds *L, size_t *lds_byt
 }
 
 // The wave-split decoder exists for the dense chains of levels 1-3 and is OPT-IN (ZPQ_DEC_PIPE=1): measured on MI355X it
-// is slower than the lane-per-component decoder (level 2 x 8192: 300 vs 269 ms; DESIGN.md 4.5 has the per-wave cycle
+// is slower than the lane-per-component decoder (level 2 x 8192: 300 vs 269 ms; EXPERIMENTS.md 4.5 has the per-wave cycle
 // breakdown) -- both are bound by the two HBM round trips per byte that nothing can be overlapped with once the LDS is
 // full of blocks, and the faster bit step leaves more of them exposed.  It stays as a third, independently written
 // device implementation that the tests compare the others with.  A block is a lane PAIR of a component wave: at most 32
