@@ -141,7 +141,8 @@ def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
 def test_full_size_batches(zpq, gpu_ctx, level, nb):
     """BASELINE.json's shapes (level 1: 4096 x 64 KiB, level 2: 8192 x 64 KiB) and the shapes bench.py's `secondary`
     ships (levels 3 and 4 at 4096 blocks, level 5 at 3072: the LINE-STORE instantiations at resident capacity -- the
-    1024 / 512-block cases run the dense ones): sampled blocks against the oracle, every block through the round trip."""
+    1024 / 512-block cases run the dense ones): at 4096 blocks EVERY coded stream against the oracle (round 4), a sample of 256
+    at level 5 and of 24 in the small cases; every block through the round trip."""
     import torch
     torch.cuda.empty_cache()                             # (earlier tests' cached buffers count against the state budget)
     model = zpq.Model(level=level)
@@ -174,10 +175,18 @@ def test_full_size_batches(zpq, gpu_ctx, level, nb):
     lens = d_len.cpu().numpy()
     outc = d_out.cpu().numpy()
     rnd = random.Random(level)
-    sample = sorted(set([0, 1, 2, 3, nb - 1, nb - 2, nb - 3, nb - 4] + [rnd.randrange(nb) for _ in range(16)]))
-    want = O.encode_blocks(model.header, [arr[i].tobytes() for i in sample], nthreads=8, slack=cap)
-    for i, w in zip(sample, want):
-        assert outc[i * cap:i * cap + int(lens[i])].tobytes() == w, i
+    if nb == 4096:
+        sample = list(range(nb))                         # the bench shapes of levels 1, 3, 4: EVERY coded stream against the oracle
+    elif nb == 3072:
+        sample = sorted(set([0, 1, 2, 3, nb - 1, nb - 2, nb - 3, nb - 4] + [rnd.randrange(nb) for _ in range(248)]))   # (level 5: the oracle maps 2 GiB per block)
+    else:
+        sample = sorted(set([0, 1, 2, 3, nb - 1, nb - 2, nb - 3, nb - 4] + [rnd.randrange(nb) for _ in range(16)]))
+    nthreads = min(16, os.cpu_count() or 1)
+    for c0 in range(0, len(sample), 1024):
+        part = sample[c0:c0 + 1024]
+        want = O.encode_blocks(model.header, [arr[i].tobytes() for i in part], nthreads=nthreads, slack=cap)
+        for i, w in zip(part, want):
+            assert int(lens[i]) == len(w) and outc[i * cap:i * cap + len(w)].tobytes() == w, i
     d_dec = torch.zeros(nb * size, dtype=torch.uint8, device=dev)
     d_dlen = torch.zeros(nb, dtype=torch.int32, device=dev)
     aux = [torch.zeros(nb, dtype=torch.int32, device=dev) for _ in range(4)]
