@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // the end of a nibble an HBM round trip -- now runs beside the chain -> squash -> coder path.  Both copies run
     // the coder (same input, same state), so the bit needs no trip between them.
 #ifdef ZPQ_NO_HYP
-    constexpr bool HYP = false;
+    constexpr bool HYP = false, HYP16 = false;
 #else
     // Round 4: the chain of five (level 3) as well, at SIXTEEN lanes per block -- ten of them the two copies of its five
     // components -- and with the line store: 16 blocks per CU are then four waves, one per SIMD, where the eight-lane
@@ -203,6 +203,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     constexpr bool TWOM = DEC && !SPEC && SP && NCH > 0;
 #else
     constexpr bool TWOM = false;
+#endif
+    // The store's PLACEMENT that goes with it -- neighbouring second-nibble contexts in one group of four slots, home slot =
+    // index & 3 -- also serves the sixteen-lane two-hypothesis decoders (-DZPQ_HYP16_NBR): the two copies' mid-byte requests then
+    // read ONE tag group and two neighbouring lines instead of two unrelated pairs.  The layout lives and dies with the launch.
+#ifdef ZPQ_HYP16_NBR
+    constexpr bool NBR = TWOM || (HYP16 && SP);
+#else
+    constexpr bool NBR = TWOM;
 #endif
     // (Requesting only the LIKELIER outcome early -- as soon as the last bit's probability is known, asking again after
     //  a wrong guess -- was measured as well: level 3 375 -> 472 ms, level 5 467 -> 557 ms.  Every speculative row read
@@ -481,9 +489,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         if (SPARSE && sp_cap) {                                                         \
             /* the line's index with the two lowest bits moved to the top (neighbouring second-nibble contexts = */ \
             /* neighbouring indices); four neighbouring indices share a home group, index & 3 is the home slot     */ \
-            const u32 tl_ = TWOM ? (((h0_ >> 6) & 3u) << sp_qbits) | (h0_ >> 8) : (h0_ >> 6); \
+            const u32 tl_ = NBR ? (((h0_ >> 6) & 3u) << sp_qbits) | (h0_ >> 8) : (h0_ >> 6); \
             key_ = tl_ + 1u;                                                            \
-            si_ = TWOM ? 4u * __umulhi((tl_ >> 2) * 0x9E3779B1u, sp_groups) + (tl_ & 3u) : __umulhi(key_ * 0x9E3779B1u, sp_cap); \
+            si_ = NBR ? 4u * __umulhi((tl_ >> 2) * 0x9E3779B1u, sp_groups) + (tl_ & 3u) : __umulhi(key_ * 0x9E3779B1u, sp_cap); \
             off_ = h0_ & 48u;                                                           \
             tags_ = *reinterpret_cast<const u32x4 *>(sp_tags + (si_ & ~3u));            \
             pox_ = (si_ << 6) + off_;                                                   \
