@@ -525,9 +525,17 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // requests the next nibble's rows.  The finished row is forwarded from registers if it
         // is one of the candidates.
         // two-hypothesis decode: the same register of the block's OTHER copy (lane ^ 1)
+        // (mov_dpp, not update_dpp(old = v, ...): every lane has a source under this permutation, and with no `old` operand
+        //  tied to the destination the compiler needs no copy of v in front of the v_mov_b32_dpp)
         auto xchg = [&](const u32 v) -> u32 {
+#ifdef ZPQ_DPP_OLD
             return (u32)__builtin_amdgcn_update_dpp((i32)v, (i32)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, false);
+#else
+            return (u32)__builtin_amdgcn_mov_dpp((i32)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);
+#endif
         };
+        const bool wr_lane = hashed && (!HYP || hyp == 0);  // this lane writes finished rows back
+        const bool mix_lane = ctype == ZT_MIX2;
         bool row_mine = true;                              // this copy requested the rows of the nibble that really follows
         // Two-hypothesis decode, a byte's SECOND nibble: its 16 possible contexts are hctx + 16 * (16..31) (predictor.v:558-560),
         // i.e. -- in the transposed layout above -- 16 neighbouring lines.  So the request need not wait for the first nibble's
@@ -653,7 +661,9 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 *reinterpret_cast<u32x4 *>(line + 48) = z4;
             }
 #ifndef ZPQ_DEBUG_NO_ROWS
-            if (have_prev && hashed && (!HYP || hyp == 0)) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;   // (both copies hold the same row)
+            // (one predicate, the lane's part of it computed once: `have_prev && hashed && ...` as written became a twenty-instruction
+            //  maze of exec-mask moves around one store)
+            if (have_prev & wr_lane) *reinterpret_cast<u32x4 *>(tbase + poff2) = Rp;   // (both copies hold the same row: copy 0 writes)
             if constexpr (HYP && TOUCHC) {
                 // the row this nibble works on counts as written from now on (it is stored when the nibble ends; until then a
                 // request that meets it takes it from the registers)
@@ -1103,7 +1113,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             R.p = is_icm ? icm_st(v, b) : 0; R.pin = 0; R.pj = 0; R.pk = 0; R.wmix = 0;
 #pragma unroll
             for (int i = 1; i < (NCH ? NCH : 1); i++) {
+#ifdef ZPQ_DPP_OLD
                 const i32 pv = __builtin_amdgcn_update_dpp(R.p, R.p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, false);
+#else
+                // (no `old` operand tied to the destination: no copy in front of the v_mov_b32_dpp.  Lanes 0 and 1 of a DPP row have
+                //  no lane two below and read 0; they, and lanes 8 and 9 where a row carries two blocks of eight, are the ICM's
+                //  copies, which use no input prediction)
+                const i32 pv = __builtin_amdgcn_mov_dpp(R.p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, true);
+#endif
                 const i32 pn = clamp2k((__mul24(w0c, pv) + (w1c << 6)) >> 16);
                 const bool me = lc == i;
                 R.pin = me ? pv : R.pin;
@@ -1169,7 +1186,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 err = (yh ? 32767 : 0) - sq;
             const i32 nw0 = clamp512k(w0 + ((__mul24(err, pin) + (1 << 12)) >> 13));
             const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
-            const u32 nv = is_icm ? (cmn | (((u32)st_new & 0x1FFu) << 23)) : (((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20));
+            // (The compiler turns these selects into a divergent if / else around the two roles' code: five exec-mask instructions
+            //  per bit.  Bitwise merges under a per-lane role mask remove them -- and were measured SLOWER: level 2 257.8-259.3
+            //  against 253.6-255.3 ms, level 1 264.8 against 258.0, level 3 334.4 against 327.5: with the if / else each role's
+            //  lanes skip the other role's LDS reads, which the merged form issues for every lane.)
+            const u32 nv_icm = cmn | (((u32)st_new & 0x1FFu) << 23), nv_isse = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
+            const u32 nv = is_icm ? nv_icm : nv_isse;
             const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
             u32 nxt_v = 0, nxt_bs = 0;
             if (K < 3) {
@@ -1184,15 +1206,17 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 Q = chain_of(nxt_v, (i32)(int8_t)(nxt_bs & 255u), X.slot * 2u + (u32)yh);
                 sq2 = s_squash[Q.p + 2048];
             }
-            // ---- the bit (both copies decode it: same code, same window, same bounds)
-            i32 y = 0;
-            if (is_last) {
+            // ---- the bit (both copies decode it: same code, same window, same bounds).  The split runs on EVERY lane -- lanes that
+            // are not a coder hold a range of their own that means nothing and is never renormalised (no memory access outside the
+            // loop) -- so that only the loop is a divergent region: one exec-mask save / branch / restore less per bit.
+            i32 y;
+            {
                 const u32 p16 = (u32)sq * 2u + 1u;
                 const u32 mid = X.low + mul_shr16(X.high - X.low, p16);
                 y = X.code <= mid ? 1 : 0;
                 X.high = y ? mid : X.high;
                 X.low = y ? X.low : mid + 1;
-                while ((X.high ^ X.low) < 0x1000000u) {
+                while (is_last && (X.high ^ X.low) < 0x1000000u) {
                     X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
                     const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c;
                 }
@@ -1206,7 +1230,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
-                if (mine && ctype == ZT_MIX2) w16s[X.slot] = (u16)w;
+                if (mine & mix_lane) w16s[X.slot] = (u16)w;
                 if (K == 3 && !MIXS) {
                     // this nibble's weights are final: write the candidates back and request the next nibble's (all sixteen
                     // lanes of the row, after the bit: hash and prefix from the coder lane, as in bitstep)
@@ -1329,7 +1353,17 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
             } else {
                 i32 eof = 0;
-                if (is_last) {
+                if constexpr (HYP) {
+                    // (as in bitstep_hyp: the split on every lane, only the renormalisation loop is a divergent region)
+                    eof = X.code <= X.low ? 1 : 0;                                                  // p=0: mid = low
+                    X.high = eof ? X.low : X.high;
+                    X.low = eof ? X.low : X.low + 1;
+                    while (is_last && (X.high ^ X.low) < 0x1000000u) {
+                        X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
+                        const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin);
+                        X.code = (X.code << 8) | c;
+                    }
+                } else if (is_last) {
                     if (X.code <= X.low) { eof = 1; X.high = X.low; } else { X.low = X.low + 1; }   // p=0: mid = low
                     while ((X.high ^ X.low) < 0x1000000u) {
                         X.low <<= 8; X.high = (X.high << 8) | 255u; if (X.low == 0) X.low = 1;
