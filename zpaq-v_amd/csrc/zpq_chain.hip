@@ -1122,14 +1122,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const i32 pv = __builtin_amdgcn_mov_dpp(R.p, 0x112 /*row_shr:2: the same copy of the component below*/, 0xf, 0xf, true);
 #endif
                 const i32 pn = clamp2k((__mul24(w0c, pv) + (w1c << 6)) >> 16);
-                const bool me = lc == i;
-                R.pin = me ? pv : R.pin;
-                R.p = me ? pn : R.p;
+                R.p = (lc == i) ? pn : R.p;
             }
+            // every lane's INPUT is the finished prediction of the lane two below: one more hop once the chain is through (it is
+            // needed by the training only, off the path to the coder) instead of a select per link
+            R.pin = __builtin_amdgcn_mov_dpp(R.p, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
             if constexpr (MIXT) {
                 // the MIX2 mixes p[NCH - 2] and p[NCH - 1] (checked on the host) of ITS copy: the lanes four and two below
-                R.pk = __builtin_amdgcn_update_dpp(R.p, R.p, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
-                R.pj = __builtin_amdgcn_update_dpp(R.p, R.p, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+                R.pk = R.pin;
+                R.pj = __builtin_amdgcn_mov_dpp(R.p, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
                 R.wmix = (i32)w16s[mslot];                    // the nibble's candidate weights live in LDS (mixw_request / mixs_arrive)
                 const i32 pm = clamp2k(wadd(wmul(R.wmix, R.pj), wmul(65536 - R.wmix, R.pk)) >> 16);
                 R.p = is_last ? pm : R.p;
