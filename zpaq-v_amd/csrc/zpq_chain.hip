@@ -922,11 +922,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 w0 = ((i32)(cur_v << 12)) >> 12;                           // ISSE lanes: sext20
             const i32 w1 = (i32)(((u32)cur_b << 12) | (cur_v >> 20));
             i32 p = is_icm ? cur_pst : 0, pin = 0;
+            // (decoders of the specialised chains, round 4: the hop without an `old` operand tied to its destination -- no copy in
+            //  front of the v_mov_b32_dpp; lane 0 of a row reads 0, it is an ICM -- and the lane's INPUT taken by one more hop once the
+            //  chain is through instead of a select per link.  See chain_of, where this was measured.)
+            constexpr bool DIET = DEC && NCH > 0;
             auto chain_step = [&](const int i) {
-                const i32 pv = row_shr1(p);
+                const i32 pv = DIET ? __builtin_amdgcn_mov_dpp(p, 0x111 /*row_shr:1*/, 0xf, 0xf, true) : row_shr1(p);
                 const i32 pn = clamp2k((__mul24(w0, pv) + (w1 << 6)) >> 16);   // |w0|<2^18, |pv|<=2^11: exact in 32 bits
                 const bool me = lc == i;
-                pin = me ? pv : pin;
+                if (!DIET) pin = me ? pv : pin;
                 p = me ? pn : p;
             };
             if constexpr (SKEW) {
@@ -937,6 +941,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             } else if (NCH) {
 #pragma unroll
                 for (int i = 1; i < (NCH ? NCH : 1); i++) chain_step(i);
+                if (DIET) pin = __builtin_amdgcn_mov_dpp(p, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
             } else {
                 for (int i = 1; i < nisse_end; i++) chain_step(i);
             }
@@ -944,7 +949,12 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             u32 mcx = 0;
             if (has_mix2) {
                 if constexpr (SKEW) { pj = pj_cur[KB]; pk = pin_cur[KB]; }
-                else {
+                else if constexpr (DIET) {
+                    // the specialised chains' MIX2 mixes the two components right below it (k = n - 2, j = n - 3: checked on the
+                    // host): two DPP hops instead of two trips through the LDS crossbar on the path to the coder
+                    pk = pin;
+                    pj = __builtin_amdgcn_mov_dpp(p, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+                } else {
                     pj = row_bcast(p, row_base + mix_j);
                     pk = row_bcast(p, row_base + mix_k);
                 }
@@ -985,7 +995,19 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
             // ---- (4) code the bit on the lane that owns the final prediction
             i32 y = yk;
-            if (is_last) {
+            if constexpr (DIET) {
+                // (as in bitstep_hyp: the split on every lane -- lanes that are no coder hold a range that means nothing and is
+                //  never renormalised -- so that only the loop is a divergent region)
+                const u32 p16 = (u32)sq * 2u + 1u;
+                const u32 mid = X.low + mul_shr16(X.high - X.low, p16);
+                y = X.code <= mid ? 1 : 0;
+                X.high = y ? mid : X.high;
+                X.low = y ? X.low : mid + 1;
+                while (is_last && (X.high ^ X.low) < 0x1000000u) {
+                    X.low <<= 8; X.high = (X.high << 8) | 255u; X.low = X.low ? X.low : 1u;
+                    const u32 c = in_byte(X.ipos); X.ipos += (X.ipos < nin); X.code = (X.code << 8) | c;
+                }
+            } else if (is_last) {
                 const u32 p16 = (u32)sq * 2u + 1u;
                 const u32 mid = X.low + mul_shr16(X.high - X.low, p16);
                 if (DEC) y = X.code <= mid ? 1 : 0;
