@@ -422,6 +422,18 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 constexpr int L = NCH + (MIXT ? 1 : 0) - 1;
                 return __builtin_amdgcn_update_dpp(v, v, L * 0x55 /*quad_perm:[L,L,L,L]*/, 0xf, 0xf, false);
             }
+            if constexpr (DEC && !HYP && NCH > 0 && GG == 8 && NCH + (MIXT ? 1 : 0) > 4) {
+                // one copy, eight lanes per block, the coder on lane 4..7 of the block: over its quad, then to the quad below
+                constexpr int P = (NCH + (MIXT ? 1 : 0) - 1) & 3;
+                v = __builtin_amdgcn_update_dpp(v, v, P * 0x55 /*quad_perm:[P,P,P,P]*/, 0xf, 0xa, false);
+                return __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+            }
+            if constexpr (DEC && !HYP && NCH == 8 && MIXT && GG == 16) {
+                // level 5: the coder (MIX2) on lane 8 of the row: over its quad, then to the two quads below
+                v = __builtin_amdgcn_update_dpp(v, v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0x4, false);
+                v = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0x2, false);
+                return __builtin_amdgcn_update_dpp(v, v, 0x108 /*row_shl:8*/, 0xf, 0x1, false);
+            }
             if (n > 1) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x101 /*row_shl:1*/, 0xf, 0xf, false); v = (bdist == 1) ? t : v; }
             if (n > 2) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x102 /*row_shl:2*/, 0xf, 0xf, false); v = (bdist >= 2 && bdist < 4) ? t : v; }
             if (n > 4) { const i32 t = __builtin_amdgcn_update_dpp(v, v, 0x104 /*row_shl:4*/, 0xf, 0xf, false); v = (bdist >= 4 && bdist < 8) ? t : v; }
@@ -1376,8 +1388,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 }
             } else {
                 i32 eof = 0;
-                if constexpr (HYP) {
-                    // (as in bitstep_hyp: the split on every lane, only the renormalisation loop is a divergent region)
+                if constexpr (NCH > 0) {
+                    // (as in the bit steps: the split on every lane, only the renormalisation loop is a divergent region)
                     eof = X.code <= X.low ? 1 : 0;                                                  // p=0: mid = low
                     X.high = eof ? X.low : X.high;
                     X.low = eof ? X.low : X.low + 1;
