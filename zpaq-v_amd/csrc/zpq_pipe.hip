@@ -290,22 +290,24 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         const u32 pa = q.po, pb = q.po ^ 16u, pc = q.po ^ 32u;
         const bool a1 = have1 && pa == L1.off, b1 = have1 && pb == L1.off, c1 = have1 && pc == L1.off;
         const bool a2 = FWD2 && have2 && pa == L2.off, b2 = FWD2 && have2 && pb == L2.off, c2 = FWD2 && have2 && pc == L2.off;
-        auto fwd = [](const bool f1, const Row &R1, const bool f2, const Row &R2, const u32x4 N) -> u32x4 {
-            return u32x4{f1 ? R1.x : (f2 ? R2.x : N.x), f1 ? R1.y : (f2 ? R2.y : N.y),
-                         f1 ? R1.z : (f2 ? R2.z : N.z), f1 ? R1.w : (f2 ? R2.w : N.w)};
-        };
-        const u32x4 A = fwd(a1, L1, a2, L2, q.A), Bq = fwd(b1, L1, b2, L2, q.B), Cq = fwd(c1, L1, c2, L2, q.C);
+        // Forwarding decides on the candidates' FIRST dwords only (check byte and priority live there); the other three dwords
+        // are forwarded for the chosen candidate alone: 20 selects per nibble instead of 32 (round 4).
+        auto fwd1 = [](const bool f1, const u32 r1, const bool f2, const u32 r2, const u32 n) -> u32 { return f1 ? r1 : (f2 ? r2 : n); };
+        const u32 Ax = fwd1(a1, L1.x, a2, L2.x, q.A.x), Bx = fwd1(b1, L1.x, b2, L2.x, q.B.x), Cx = fwd1(c1, L1.x, c2, L2.x, q.C.x);
         const u32 chk = q.chk;
-        const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
-        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+        const bool ma = (Ax & 255u) == chk, mb = (Bx & 255u) == chk, mc = (Cx & 255u) == chk;
+        const u32 qa = (Ax >> 8) & 255u, qb = (Bx >> 8) & 255u, qc = (Cx >> 8) & 255u;
         const bool va = qa <= qb && qa <= qc, vb = qb < qc;             // victim order (predictor.v:513-531)
         const bool hit = ma || mb || mc;
         const bool ua = ma || (!hit && va);
         const bool ub = !ua && (mb || (!hit && vb));
         Row R;
         R.off = ua ? pa : (ub ? pb : pc);
-        const u32 Rx = ua ? A.x : (ub ? Bq.x : Cq.x), Ry = ua ? A.y : (ub ? Bq.y : Cq.y);
-        const u32 Rz = ua ? A.z : (ub ? Bq.z : Cq.z), Rw = ua ? A.w : (ub ? Bq.w : Cq.w);
+        const bool g1 = ua ? a1 : (ub ? b1 : c1), g2 = ua ? a2 : (ub ? b2 : c2);     // the chosen candidate is a row still in registers
+        const u32 Rx = ua ? Ax : (ub ? Bx : Cx);
+        const u32 Ry = fwd1(g1, L1.y, g2, L2.y, ua ? q.A.y : (ub ? q.B.y : q.C.y));
+        const u32 Rz = fwd1(g1, L1.z, g2, L2.z, ua ? q.A.z : (ub ? q.B.z : q.C.z));
+        const u32 Rw = fwd1(g1, L1.w, g2, L2.w, ua ? q.A.w : (ub ? q.B.w : q.C.w));
         R.x = hit ? Rx : chk; R.y = hit ? Ry : 0u; R.z = hit ? Rz : 0u; R.w = hit ? Rw : 0u;
         u32 poff2 = L1.off, cpo = q.po & ~63u;
         asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(poff2), "+v"(cpo) : "v"(R.x), "v"(R.w));
@@ -560,22 +562,24 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
         const u32 pa = q.po, pb = q.po ^ 16u, pc = q.po ^ 32u;
         const bool a1 = have1 && pa == L1.off, b1 = have1 && pb == L1.off, c1 = have1 && pc == L1.off;
         const bool a2 = have2 && pa == L2.off, b2 = have2 && pb == L2.off, c2 = have2 && pc == L2.off;
-        auto fwd = [](const bool f1, const Row &R1, const bool f2, const Row &R2, const u32x4 N) -> u32x4 {
-            return u32x4{f1 ? R1.x : (f2 ? R2.x : N.x), f1 ? R1.y : (f2 ? R2.y : N.y),
-                         f1 ? R1.z : (f2 ? R2.z : N.z), f1 ? R1.w : (f2 ? R2.w : N.w)};
-        };
-        const u32x4 A = fwd(a1, L1, a2, L2, q.A), Bq = fwd(b1, L1, b2, L2, q.B), Cq = fwd(c1, L1, c2, L2, q.C);
+        // Forwarding decides on the candidates' FIRST dwords only (check byte and priority live there); the other three dwords
+        // are forwarded for the chosen candidate alone: 20 selects per nibble instead of 32 (round 4).
+        auto fwd1 = [](const bool f1, const u32 r1, const bool f2, const u32 r2, const u32 n) -> u32 { return f1 ? r1 : (f2 ? r2 : n); };
+        const u32 Ax = fwd1(a1, L1.x, a2, L2.x, q.A.x), Bx = fwd1(b1, L1.x, b2, L2.x, q.B.x), Cx = fwd1(c1, L1.x, c2, L2.x, q.C.x);
         const u32 chk = q.chk;
-        const bool ma = (A.x & 255u) == chk, mb = (Bq.x & 255u) == chk, mc = (Cq.x & 255u) == chk;
-        const u32 qa = (A.x >> 8) & 255u, qb = (Bq.x >> 8) & 255u, qc = (Cq.x >> 8) & 255u;
+        const bool ma = (Ax & 255u) == chk, mb = (Bx & 255u) == chk, mc = (Cx & 255u) == chk;
+        const u32 qa = (Ax >> 8) & 255u, qb = (Bx >> 8) & 255u, qc = (Cx >> 8) & 255u;
         const bool va = qa <= qb && qa <= qc, vb = qb < qc;             // victim order (predictor.v:513-531)
         const bool hit = ma || mb || mc;
         const bool ua = ma || (!hit && va);
         const bool ub = !ua && (mb || (!hit && vb));
         Row R;
         R.off = ua ? pa : (ub ? pb : pc);
-        const u32 Rx = ua ? A.x : (ub ? Bq.x : Cq.x), Ry = ua ? A.y : (ub ? Bq.y : Cq.y);
-        const u32 Rz = ua ? A.z : (ub ? Bq.z : Cq.z), Rw = ua ? A.w : (ub ? Bq.w : Cq.w);
+        const bool g1 = ua ? a1 : (ub ? b1 : c1), g2 = ua ? a2 : (ub ? b2 : c2);     // the chosen candidate is a row still in registers
+        const u32 Rx = ua ? Ax : (ub ? Bx : Cx);
+        const u32 Ry = fwd1(g1, L1.y, g2, L2.y, ua ? q.A.y : (ub ? q.B.y : q.C.y));
+        const u32 Rz = fwd1(g1, L1.z, g2, L2.z, ua ? q.A.z : (ub ? q.B.z : q.C.z));
+        const u32 Rw = fwd1(g1, L1.w, g2, L2.w, ua ? q.A.w : (ub ? q.B.w : q.C.w));
         R.x = hit ? Rx : chk; R.y = hit ? Ry : 0u; R.z = hit ? Rz : 0u; R.w = hit ? Rw : 0u;
         u32 poff2 = L1.off;
         asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(poff2) : "v"(R.x), "v"(R.w));
