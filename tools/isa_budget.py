@@ -76,6 +76,7 @@ def source_ranges(src_path):
         ("nibble_begin (first entry)", "auto nibble_begin = [&]"),
         ("MIX2 weights", "auto mix_byte_begin = [&]"),
         ("bitstep (plain / pipelined)", "auto bitstep = [&]"),
+        ("hyp: chain p0 -> p1 -> ... (chain_of)", "auto chain_of = [&]"),
         ("bitstep_hyp", "auto bitstep_hyp = [&]"),
         ("step dispatch", "auto step = [&]"),
         ("byte loop (EOF flag, window, bookkeeping)", "prefetch_rows(0u, 1u);"),
@@ -88,7 +89,7 @@ def source_ranges(src_path):
     # finer roles inside bitstep_hyp, by its own comments
     hyp0 = find("auto bitstep_hyp = [&]")
     if hyp0:
-        sub = [("hyp: chain p0 -> p1 -> ...", "const u32 s = cur_s;", hyp0),
+        sub = [("hyp: entry unpack, chain call", "const u32 s = cur_s;", hyp0),
                ("hyp: squash lookup", "const i32 sq = s_squash[p + 2048];", hyp0),
                ("hyp: own outcome: next state + entry fetch", "// ---- this copy's outcome", hyp0),
                ("hyp: own outcome: train counter / weights", "const u32 cmn = (u32)wadd((i32)cmv", hyp0),
@@ -182,7 +183,7 @@ def main():
     if not loops:
         raise SystemExit("no loop found")
     # the byte loop = the innermost loop that contains every instruction generated from the bit steps
-    bits = [i for i, (op, k, ln, ch, tgt) in enumerate(insts) if role_of(ln).startswith(("hyp:", "bitstep"))]
+    bits = [i for i, (op, k, ln, ch, tgt) in enumerate(insts) if role_of(ln).startswith(("hyp:", "bitstep")) and "chain_of" not in role_of(ln)]
     if not bits:
         raise SystemExit("no bit-step instructions found in this kernel")
     cover = [(x, y) for (x, y) in loops if x <= min(bits) and max(bits) <= y]
