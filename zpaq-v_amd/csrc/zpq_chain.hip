@@ -1271,7 +1271,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
-                if (mine & mix_lane) w16s[X.slot] = (u16)w;
+                w16s[(mine & mix_lane) ? X.slot : 0u] = (u16)w;           // (slot 0 holds no candidate: everybody else's store lands there; level 4 433.6 -> 431.0 ms)
                 if (K == 3 && !MIXS) {
                     // this nibble's weights are final: write the candidates back and request the next nibble's (all sixteen
                     // lanes of the row, after the bit: hash and prefix from the coder lane, as in bitstep)
