@@ -976,7 +976,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
                 } else if (DEC && mixreg) {
                     wmix = (i32)w16s[X.slot];
-                    if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                    const i32 pm = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                    p = is_last ? pm : p;                             // (a select on every lane, not a divergent region for one)
                 } else if (is_last) {
                     mcx = (hctx + (X.c8 & mix_mask)) & mix_cmask;
                     wmix = a16[mcx];
@@ -1070,7 +1071,14 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             const i32 nb = is_icm ? (st_new >> 9) : (nw1 >> 12);
             t32[s] = nv;
             t8[s] = (u8)nb;
-            if (has_mix2 && ctype == ZT_MIX2) {
+            if constexpr (DIET && MIXT) {
+                // (specialised decoders: the weight's training on every lane, the store under an index select -- slot 0 holds no
+                //  candidate -- instead of a divergent region for the MIX2's one lane)
+                const i32 em = wmul(err, mix_rate) >> 5;
+                i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                w = min(max(w, 0), 65535);
+                w16s[(ctype == ZT_MIX2) ? X.slot : 0u] = (u16)w;
+            } else if (has_mix2 && ctype == ZT_MIX2) {
                 const i32 em = wmul(err, mix_rate) >> 5;
                 i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
