@@ -55,6 +55,10 @@ namespace zpqc {
 
 __device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 wmul(i32 a, i32 b) { return (i32)((u32)a * (u32)b); }
+// The MIX2's products in the specialised decoders: a weight (<= 65536) or an error term (|err| < 2^15, rate < 2^8, |em| < 2^18) times a
+// prediction or a difference of two (|p| <= 2048, |pj - pk| < 2^12): every operand fits 24 signed bits and no product leaves 32 -- the
+// full-rate 24-bit multiply is exact where V's wrapping 32-bit multiply (a quarter-rate v_mul_lo_u32 / v_mad_u64_u32) is.
+__device__ __forceinline__ i32 mul24x(i32 a, i32 b) { return __mul24(a, b); }
 __device__ __forceinline__ i32 clamp2k(i32 x) { return min(max(x, -2048), 2047); }
 // (u64(range) * p16) >> 16 for p16 < 2^16 (encoder.v:60-61, decoder.v:86-87) without the 64-bit multiply:
 // range = hi * 2^16 + lo  =>  hi * p16 + ((lo * p16) >> 16), both products of 16-bit operands (two full-rate v_mul_u32_u24)
@@ -976,7 +980,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                     if (is_last) p = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
                 } else if (DEC && mixreg) {
                     wmix = (i32)w16s[X.slot];
-                    const i32 pm = clamp2k(wadd(wmul(wmix, pj), wmul(65536 - wmix, pk)) >> 16);
+                    const i32 pm = clamp2k(wadd(mul24x(wmix, pj), mul24x(65536 - wmix, pk)) >> 16);
                     p = is_last ? pm : p;                             // (a select on every lane, not a divergent region for one)
                 } else if (is_last) {
                     mcx = (hctx + (X.c8 & mix_mask)) & mix_cmask;
@@ -1074,8 +1078,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             if constexpr (DIET && MIXT) {
                 // (specialised decoders: the weight's training on every lane, the store under an index select -- slot 0 holds no
                 //  candidate -- instead of a divergent region for the MIX2's one lane)
-                const i32 em = wmul(err, mix_rate) >> 5;
-                i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                const i32 em = mul24x(err, mix_rate) >> 5;
+                i32 w = wadd(wmix, wadd(mul24x(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
                 w16s[(ctype == ZT_MIX2) ? X.slot : 0u] = (u16)w;
             } else if (has_mix2 && ctype == ZT_MIX2) {
@@ -1174,7 +1178,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
                 R.pk = R.pin;
                 R.pj = __builtin_amdgcn_mov_dpp(R.p, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
                 R.wmix = (i32)w16s[mslot];                    // the nibble's candidate weights live in LDS (mixw_request / mixs_arrive)
-                const i32 pm = clamp2k(wadd(wmul(R.wmix, R.pj), wmul(65536 - R.wmix, R.pk)) >> 16);
+                const i32 pm = clamp2k(wadd(mul24x(R.wmix, R.pj), mul24x(65536 - R.wmix, R.pk)) >> 16);
                 R.p = is_last ? pm : R.p;
             }
             return R;
@@ -1276,8 +1280,8 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
             }
             if constexpr (MIXT) {
                 // MIX2 weight (predictor.v:744-762), trained by the copy that was right
-                const i32 em = wmul(err, mix_rate) >> 5;
-                i32 w = wadd(wmix, wadd(wmul(em, pj - pk), 1 << 12) >> 13);
+                const i32 em = mul24x(err, mix_rate) >> 5;
+                i32 w = wadd(wmix, wadd(mul24x(em, pj - pk), 1 << 12) >> 13);
                 w = min(max(w, 0), 65535);
                 w16s[(mine & mix_lane) ? X.slot : 0u] = (u16)w;           // (slot 0 holds no candidate: everybody else's store lands there; level 4 433.6 -> 431.0 ms)
                 if (K == 3 && !MIXS) {
