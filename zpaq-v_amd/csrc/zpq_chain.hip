@@ -133,21 +133,42 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const int tid = threadIdx.x, nthr = blockDim.x;
 
     // ---- shared read-only tables -> LDS
+    // Level 1's decoders (two components, at most 32 blocks of 2.6 KiB per workgroup) have the LDS to spare for the WHOLE
+    // stretch table, 32768 x i16: one lookup instead of the sixteen instructions that unpack the 8.5 KiB form.
+#ifdef ZPQ_NO_DST
+    constexpr bool DST = false;
+#else
+    constexpr bool DST = DEC && NCH == 2;
+#endif
+    constexpr int L_SQUASH = DST ? LDS_DST_BYTES : LDS_SQUASH;
+    constexpr int L_NS = L_SQUASH + 4096 * 2, L_STATE = L_NS + 1024;
+    static_assert(DST || L_STATE == LDS_STATE, "layout");
     {
-        u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
-        for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
-        u16 *sq = reinterpret_cast<u16 *>(lds + LDS_SQUASH);
+        if constexpr (DST) {
+            u32 *st = reinterpret_cast<u32 *>(lds);
+            const u32 *src = reinterpret_cast<const u32 *>(B.stretch);
+            for (int i = tid; i < 16384; i += nthr) st[i] = src[i];
+            __syncthreads();
+            if (tid == 0) reinterpret_cast<int16_t *>(lds)[0] = B.stretch[1];              // stretch(0) = stretch(1) (predictor.v:205-214)
+        } else {
+            u32 *st = reinterpret_cast<u32 *>(lds + LDS_STRETCH);
+            for (int i = tid; i < 2048 + 128; i += nthr) st[i] = B.stretch_c[i];
+        }
+        u16 *sq = reinterpret_cast<u16 *>(lds + L_SQUASH);
         for (int i = tid; i < 4096; i += nthr) sq[i] = (u16)B.squash[min(max(i - 1, 0), 4093)];   // entry p + 2048 = squash(p): no clamp in the bit loop (|p| <= 2048)
-        u8 *ns = lds + LDS_NS;
+        u8 *ns = lds + L_NS;
         for (int i = tid; i < 1024; i += nthr) ns[i] = B.ns[i];
     }
     __syncthreads();
     const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
-    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
-    const u8 *s_ns = lds + LDS_NS;
+    const u16 *s_squash = reinterpret_cast<const u16 *>(lds + L_SQUASH);
+    const u8 *s_ns = lds + L_NS;
 
-    // stretch(cm >> 8) from the 8.5 KiB LDS packing (predictor.v:205-214); `cm` may be any u32
+    // stretch(cm >> 8) (predictor.v:205-214) from the 8.5 KiB LDS packing, or from the whole table (DST; a counter is below
+    // 2^23, garbage on lanes that hold none is cut to the table); `cm` may be any u32
     auto stretch_of = [&](u32 cm) -> i32 {
+        if constexpr (DST) return reinterpret_cast<const int16_t *>(lds)[(cm >> 8) & 32767u];
+#ifdef ZPQ_STRETCH_ENDS
         u32 q = cm >> 8;
         q = min(max(q, 1u), 32767u);
         const u32 wv = s_stretch[q >> 4];
@@ -155,6 +176,15 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
         const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
         return (q < 64u || q >= 32704u) ? endv : midv;
+#else
+        // The table rises by at most 1 per entry everywhere but at its last one (stretch(32767) = 2047 after 375; checked
+        // exhaustively where the packing is built, zpq_model.cpp) -- and no ICM counter gets there: cminit's largest is
+        // 31987 << 8 (checked there too), and an update adds (32767 - q) >> 2 to cm = 256 q + r, which cannot carry q to 32767 (that needs
+        // 255 + d / 4 >= 256 d for d = 32767 - q >= 1).  So: word q >> 4 = base + 15 step bits, eight instructions;
+        // word 0's base is stretch(1), which is also the reference's stretch(0) (predictor.v:205-214).
+        const u32 wv = s_stretch[(cm >> 12) & 2047u];
+        return ((i32)wv >> 16) + (i32)__popc(__builtin_amdgcn_ubfe(wv, 1u, (cm >> 8) & 15u));
+#endif
     };
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / G, li = lane % G;
@@ -163,7 +193,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     const int slot_id = blockIdx.x * cfg.blocks_per_wg + bslot;
     const int nslots = B.nslots;                       // may be less than gridDim.x * blocks_per_wg
     u8 *slot = B.slots + (u64)slot_id * M.slot_bytes;
-    u8 *my = lds + LDS_STATE + bslot * cfg.lds_per_block;
+    u8 *my = lds + L_STATE + bslot * cfg.lds_per_block;
 
     const int n = NCH ? NCH + (MIXT ? 1 : 0) : cfg.n;
     const int last = n - 1;
@@ -260,7 +290,7 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
     // t32[s] = cm | (st & 0x1FF) << 23, t8[s] = st >> 9 -- the table lookup behind stretch then sits
     // in the update phase instead of in front of the prediction chain.  Lanes without a table
     // (idle, MIX2) use per-workgroup dummy tables, so the bit loop needs no role branches.
-    u8 *dummy = lds + LDS_STATE + cfg.lds_dummy;
+    u8 *dummy = lds + L_STATE + cfg.lds_dummy;
     u32 *t32 = reinterpret_cast<u32 *>(hashed ? my + cfg.lds_off32[lc] : dummy);
     u8 *t8 = hashed ? my + cfg.lds_off8[lc] : dummy + 1024;
     u16 *a16 = reinterpret_cast<u16 *>(slot + C.a16_off);
@@ -1616,7 +1646,9 @@ static bool build_cfg(const DModel *M, Cfg *cfg)
         cfg->g = (want == 8 && M->n <= 8) ? 8 : 16;
     }
     const int bpwave2 = 64 / cfg->g;   // blocks one wave carries
-    const int avail = 160 * 1024 - zpqc::LDS_STATE - 1280 /*dummy tables*/ - 256;
+    // (the level-1 decoders stage the whole stretch table: LDS_DST_BYTES instead of the 8.5 KiB packing)
+    const int shared_tables = cfg->nch_spec == 2 ? zpqc::LDS_STATE - zpqc::LDS_SQUASH + zpqc::LDS_DST_BYTES : zpqc::LDS_STATE;
+    const int avail = 160 * 1024 - shared_tables - 1280 /*dummy tables*/ - 256;
     int bpw = avail / cfg->lds_per_block;
     if (bpw > 32) bpw = 32;                                           // 8 waves of 4 blocks or 4 waves of 8
     bpw = bpw / bpwave2 * bpwave2;
@@ -1719,7 +1751,14 @@ extern "C" int zpq_launch_chain(const DBatch *B, const DModel *hostM, int decode
     cfg.blocks_per_wg = blocks_per_wg;
     cfg.lds_dummy = blocks_per_wg * cfg.lds_per_block;
     const int threads = cfg.blocks_per_wg / (64 / cfg.g) * 64;
-    const size_t lds = (size_t)zpqc::LDS_STATE + (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
+#ifdef ZPQ_NO_DST
+    const bool dst = false;
+#else
+    const bool dst = decode && cfg.nch_spec == 2;
+#endif
+    const size_t lds = (size_t)zpqc::LDS_STATE + (dst ? (size_t)(zpqc::LDS_DST_BYTES - zpqc::LDS_SQUASH) : 0) +
+                       (size_t)cfg.blocks_per_wg * cfg.lds_per_block + 1280;
+    if (lds > 160 * 1024) return ZPQ_E_INTERNAL;
     // encode uses the pipelined bit step, decode the plain one (measured, see above)
 #define ZPQ_LAUNCH(D, N, MX, GGv, SPv)                                                                   \
     do {                                                                                                 \

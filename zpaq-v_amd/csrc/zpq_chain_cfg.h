@@ -24,6 +24,7 @@ constexpr int LDS_STRETCH = 0;                   // u32[2048+128]
 constexpr int LDS_SQUASH = (2048 + 128) * 4;     // u16[4096]
 constexpr int LDS_NS = LDS_SQUASH + 4096 * 2;    // u8[1024]
 constexpr int LDS_STATE = LDS_NS + 1024;         // per-block state follows (16-B aligned)
+constexpr int LDS_DST_BYTES = 32768 * 2;         // the whole stretch table as i16 (level 1's decoders, in place of the packing)
 
 // HCOMP program shapes the kernel evaluates in registers instead of interpreting
 enum { VM_GENERIC = 0, VM_HASHCHAIN = 1, VM_LEVEL1 = 2 };

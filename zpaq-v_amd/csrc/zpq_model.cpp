@@ -190,6 +190,26 @@ static void build_tables()
         const int step = T.stretch[p] - T.stretch[p - 1];
         if ((p & 15) && step != 0 && step != 1) g_tab_status = ZPQ_E_INTERNAL;
     }
+    // k_chain decodes EVERY index below 32767 from the packed words (the table's only step above 1 is its last one, and no
+    // ICM counter reaches it): word 0 starts at stretch(1), which is what the reference returns for index 0 as well
+    // (predictor.v:205-214).  The decode, exhaustively:
+    {
+        const int base = T.stretch[1];
+        uint32_t bits = 0;
+        for (int k = 2; k < 16; k++)
+            if (T.stretch[k] != T.stretch[k - 1]) bits |= 1u << k;
+        T.stretch_c[0] = ((uint32_t)(uint16_t)(int16_t)base << 16) | bits;
+    }
+    for (int q = 0; q < 32767; q++) {
+        const uint32_t wv = T.stretch_c[q >> 4];
+        const uint32_t k = q & 15, field = (wv >> 1) & ((1u << k) - 1u);
+        const int v = ((int32_t)wv >> 16) + __builtin_popcount(field);
+        if (v != T.stretch[q < 1 ? 1 : q]) g_tab_status = ZPQ_E_INTERNAL;
+    }
+    for (int st = 0; st < 256; st++) {                                           // an ICM counter starts below index 32767 (and
+        const uint32_t n0 = T.ns[st * 4 + 2], n1 = T.ns[st * 4 + 3];              // no update carries it there: zpq_chain.hip)
+        if (((((n1 * 2 + 1) << 22) / (n0 + n1 + 1)) >> 8) >= 32767u) g_tab_status = ZPQ_E_INTERNAL;
+    }
 }
 
 const Tables &tables(int *status)

@@ -147,6 +147,7 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
     const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
     const u8 *s_ns = lds + LDS_NS;
     auto stretch_of = [&](u32 cm) -> i32 {                              // see zpq_chain.hip
+#ifdef ZPQ_STRETCH_ENDS
         u32 q = cm >> 8;
         q = min(max(q, 1u), 32767u);
         const u32 wv = s_stretch[q >> 4];
@@ -154,6 +155,10 @@ __device__ __forceinline__ void comp_loop(const StageArgs &S)
         const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
         const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
         return (q < 64u || q >= 32704u) ? endv : midv;
+#else
+        const u32 wv = s_stretch[(cm >> 12) & 2047u];                   // (an ICM counter's index stays below 32767)
+        return ((i32)wv >> 16) + (i32)__popc(__builtin_amdgcn_ubfe(wv, 1u, (cm >> 8) & 15u));
+#endif
     };
     const int ci = S.ci;
     const DComp &C = M.comp[ci];
@@ -702,6 +707,7 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
     const u16 *s_squash = reinterpret_cast<const u16 *>(lds + LDS_SQUASH);
     const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
     auto stretch_of = [&](u32 cm) -> i32 {                              // see zpq_chain.hip
+#ifdef ZPQ_STRETCH_ENDS
         u32 q = cm >> 8;
         q = min(max(q, 1u), 32767u);
         const u32 wv = s_stretch[q >> 4];
@@ -709,6 +715,10 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
         const i32 endv = (i32)(int16_t)s_stretch[2048 + (ei & 127u)];
         const i32 midv = (i32)(int16_t)(wv >> 16) + __popc(wv & ((2u << (q & 15u)) - 1u) & 0xFFFEu);
         return (q < 64u || q >= 32704u) ? endv : midv;
+#else
+        const u32 wv = s_stretch[(cm >> 12) & 2047u];                   // (an ICM counter's index stays below 32767)
+        return ((i32)wv >> 16) + (i32)__popc(__builtin_amdgcn_ubfe(wv, 1u, (cm >> 8) & 15u));
+#endif
     };
     const int ci = S.ci;
     u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
