@@ -32,7 +32,7 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
             continue
         role = "decode" if "k_chain<true" in k else "encode"
         if role == "encode":
-            enc_name = "k_pipe<encode>" if "k_pipe" in k else "k_chain<encode>"
+            enc_name = ("k_pipe2<encode>" if "k_pipe2" in k else "k_pipe<encode>") if "k_pipe" in k else "k_chain<encode>"
         agg[role][r["Counter_Name"]] += float(r["Counter_Value"]) / LAUNCHES
 pmc = {}
 for role in ("encode", "decode"):

@@ -698,7 +698,9 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
 }
 
 // the counter / weights half of a stage (see hist_loop): states from its history wave, an ISSE's inputs from its predecessor
-template <int NCH, bool HIO, bool IS_LAST, bool IS_ICM>
+// PAIR (round 4): the wave's two halves are the weights of two ISSEs (lane = block in both halves, S.ci per lane): whether the
+// stage is the chain's last one is then a per-lane fact
+template <int NCH, bool HIO, bool IS_LAST, bool IS_ICM, bool PAIR = false>
 __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
 {
     const DBatch &B = *S.B;
@@ -721,8 +723,9 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
 #endif
     };
     const int ci = S.ci;
-    u32 *const t32 = reinterpret_cast<u32 *>(S.my + cfg.lds_off32[ci]);
-    u8 *const t8 = S.my + cfg.lds_off8[ci];
+    const bool is_last = PAIR ? ci == NCH - 1 : IS_LAST;
+    u32 *const t32 = reinterpret_cast<u32 *>(S.my + (PAIR ? (ci == 2 ? cfg.lds_off32[2] : cfg.lds_off32[1]) : cfg.lds_off32[ci]));
+    u8 *const t8 = S.my + (PAIR ? (ci == 2 ? cfg.lds_off8[2] : cfg.lds_off8[1]) : cfg.lds_off8[ci]);
     const uint2 *const st_in = reinterpret_cast<const uint2 *>(lds + S.L.st_off) + (size_t)ci * 2 * S.bpw + S.lane;
     const uint4 *const link_in = reinterpret_cast<const uint4 *>(lds + S.L.link_off) + (size_t)(ci > 0 ? ci - 1 : 0) * 2 * S.bpw + S.lane;
     uint4 *const link_out = reinterpret_cast<uint4 *>(lds + S.L.link_off) + (size_t)ci * 2 * S.bpw + S.lane;
@@ -781,7 +784,7 @@ __device__ __forceinline__ void pred_loop(const StageArgs &S, const int delay)
                     const i32 nw1 = clamp512k(w1 + ((err + 16) >> 5));
                     nv = ((u32)nw0 & 0xFFFFFu) | ((u32)nw1 << 20);
                     nb = nw1 >> 12;
-                    outv = IS_LAST ? (u32)sq | (yk << 15) : (u32)p;
+                    outv = is_last ? (u32)sq | (yk << 15) : (u32)p;
                 }
                 {
                     const u32 ov = (outv & 0xFFFFu) << ((kb & 1) * 16);
@@ -1088,7 +1091,14 @@ __global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, co
     }
     __syncthreads();
     const u32 *s_stretch = reinterpret_cast<const u32 *>(lds + LDS_STRETCH);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int wave = tid >> 6;
+    // role of this wave: 1 = history of component comp, 2 = counter / weights of component comp, 3 = coder
+    // (cfg.split_enc: four bits per wave, role id 0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 + c: component c whole |
+    //  12 H1+H2 | 13 P1+P2: a PAIRED wave -- both ISSEs of a three-component chain run the same code, so lanes 0-31 are
+    //  component 1 and lanes 32-63 component 2 of the workgroup's (at most 32) blocks: five roles instead of seven)
+    const int rid = (int)(((u64)cfg.split_enc >> (4 * wave)) & 15u);
+    const bool paired = NCH == 3 && (rid == 12 || rid == 13);
+    const int lane = paired ? (tid & 31) : (tid & 63);
     const int bpw = cfg.blocks_per_wg;
     const int wg_slot0 = blockIdx.x * bpw;
     const int nslots = B.nslots;
@@ -1098,11 +1108,8 @@ __global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, co
     u8 *const my = lds + LDS_STATE + (lane_on ? lane : 0) * cfg.lds_per_block;
     u32 *const misc = reinterpret_cast<u32 *>(lds + L.misc_off);
     const int wg_slots = min(bpw, nslots - wg_slot0);
-    // role of this wave: 1 = history of component comp, 2 = counter / weights of component comp, 3 = coder
-    // (cfg.split_enc: four bits per wave, role id 0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 + c: component c whole)
-    const int rid = (int)(((u64)cfg.split_enc >> (4 * wave)) & 15u);
-    const int role = rid == 6 ? 3 : (rid >= 8 ? 0 : ((rid & 1) ? 2 : 1));
-    const int comp = rid == 6 ? 0 : (rid >= 8 ? rid - 8 : (rid >> 1));
+    const int role = rid == 6 ? 3 : (paired ? (rid == 12 ? 1 : 2) : (rid >= 8 ? 0 : ((rid & 1) ? 2 : 1)));
+    const int comp = rid == 6 ? 0 : (paired ? 1 + ((tid >> 5) & 1) : (rid >= 8 ? rid - 8 : (rid >> 1)));
     // delays: a whole stage works one iteration behind its predecessor's output, a split one's weights wave too, its history
     // wave one iteration ahead of that; split_mask bit c = component c is split
     int dH[3] = {0, 0, 0}, dP[3] = {0, 0, 0}, dC = 0;
@@ -1164,7 +1171,7 @@ __global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, co
         __syncthreads();
         S.iters = *misc + (u32)dC;
         S.split = (HIO && B.gate_flag) ? (B.gate_pos > 64u ? B.gate_pos - 64u : 0u) : S.iters;
-        S.delay = dP[comp];
+        S.delay = comp == 0 ? dP[0] : (comp == 1 ? dP[1] : dP[2]);
 
         Coder X;
         X.low = 1; X.high = 0xFFFFFFFFu; X.opos = 0; X.cap = S.cap; X.dst = S.dst;
@@ -1173,9 +1180,10 @@ __global__ void __launch_bounds__(64 * (2 * NCH + 1)) k_pipe2(const DBatch B, co
             else if (comp == NCH - 1) comp_loop<NCH, false, HIO, false, true, false>(S);
             else comp_loop<NCH, false, HIO, false, false, false>(S);
         }
-        else if (role == 1) hist_loop<NCH, HIO>(S, dH[comp]);
+        else if (role == 1) hist_loop<NCH, HIO>(S, comp == 0 ? dH[0] : (comp == 1 ? dH[1] : dH[2]));
         else if (role == 2) {
-            if (comp == 0) pred_loop<NCH, HIO, false, true>(S, dP[comp]);
+            if (paired) pred_loop<NCH, HIO, false, false, true>(S, comp == 2 ? dP[2] : dP[1]);
+            else if (comp == 0) pred_loop<NCH, HIO, false, true>(S, dP[comp]);
             else if (comp == NCH - 1) pred_loop<NCH, HIO, true, false>(S, dP[comp]);
             else pred_loop<NCH, HIO, false, false>(S, dP[comp]);
         }
@@ -1250,9 +1258,14 @@ static bool split_order_valid(const char *order, int nch)
 {
     int whole[3] = {0, 0, 0}, hist[3] = {0, 0, 0}, pred[3] = {0, 0, 0}, coder = 0, nw = 0;
     for (const char *q = order; *q; q++, nw++) {
-        const int id = *q == 'a' ? 10 : (*q >= '0' && *q <= '9') ? *q - '0' : -1;
+        const int id = *q == 'a' ? 10 : *q == 'c' ? 12 : *q == 'd' ? 13 : (*q >= '0' && *q <= '9') ? *q - '0' : -1;
         if (id < 0 || id == 7) return false;
         if (id == 6) { coder++; continue; }
+        if (id >= 12) {                                      // both ISSEs of a three-component chain on one wave's two halves
+            if (nch != 3) return false;
+            if (id == 12) { hist[1]++; hist[2]++; } else { pred[1]++; pred[2]++; }
+            continue;
+        }
         const int c = id >= 8 ? id - 8 : id >> 1;
         if (c >= nch || c > 2) return false;
         if (id >= 8) whole[c]++; else if (id & 1) pred[c]++; else hist[c]++;
@@ -1288,23 +1301,27 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
     // blocks.  Level 2 has seven such roles for four SIMDs; every order and every mix of split and whole stages that was
     // tried ran at 122-137 ms against 123 for k_pipe (two waves sharing a SIMD issue slower together than the instruction
     // counts promise), so it stays on k_pipe.  ZPQ_ENC_SPLIT=0: never split; ZPQ_ENC_SPLIT=<role ids, wave 0 first>: that
-    // order (0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 W0 | 9 W1 | a W2 = whole stages), levels 1-2.
+    // order (0 H0 | 1 P0 | 2 H1 | 3 P1 | 4 H2 | 5 P2 | 6 coder | 8 W0 | 9 W1 | a W2 = whole stages | c H1+H2 | d P1+P2 = both
+    // ISSEs of level 2 on the two halves of one wave), levels 1-2.
     {
         const char *ev = getenv("ZPQ_ENC_SPLIT");
         cfg.split_enc = 0;
         if (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0 && strlen(ev) == 1)) {
-            const char *order = cfg.nch_spec == 2 ? "60231" : nullptr;
+            // (level 2, round 4: both ISSEs on the two halves of one wave, "60cd1": five roles, coder + ICM counters on one SIMD as at level 1)
+            const char *order = cfg.nch_spec == 2 ? "60231" : (blocks_per_wg <= 32 ? "60cd1" : nullptr);
             if (ev && strlen(ev) >= 4) {
-                if (split_order_valid(ev, cfg.nch_spec)) order = ev;
+                const bool has_pair = strchr(ev, 'c') || strchr(ev, 'd');   // (a paired wave holds 2 x 32 blocks at most)
+                if (split_order_valid(ev, cfg.nch_spec) && !(has_pair && blocks_per_wg > 32)) order = ev;
                 else fprintf(stderr, "[zpaq_hip] ZPQ_ENC_SPLIT=%s is not a complete wave order for %d components: ignored\n", ev, cfg.nch_spec);
             }
             if (order) {
                 uint64_t v = 0;
                 int mask = 0, nw = 0;
                 for (int w = 0; order[w]; w++, nw++) {
-                    const int id = order[w] == 'a' ? 10 : order[w] - '0';
+                    const int id = order[w] == 'a' ? 10 : order[w] == 'c' ? 12 : order[w] == 'd' ? 13 : order[w] - '0';
                     v |= (uint64_t)id << (4 * w);
                     if (id < 6) mask |= 1 << (id >> 1);
+                    else if (id >= 12) mask |= 6;
                 }
                 cfg.split_enc = (int64_t)(v | ((uint64_t)mask << 32) | ((uint64_t)nw << 40) | (1ull << 48));
             }
