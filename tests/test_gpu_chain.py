@@ -46,7 +46,7 @@ def test_chain_matches_golden_streams(zpq, gpu_ctx, level):
         blocks = [INPUTS[k.split("/")[1]] for k in ks]
         flags = zpq.FLAG_PP if mode == "pp" else 0
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks, flags=flags)
-        pipe = "k_pipe2<encode>" if level in (1, 2) else "k_pipe<encode>"     # (levels 1-2, dense: stages split into history and weights waves)
+        pipe = "k_pipe2<encode>" if level == 1 else "k_pipe<encode>"     # (level 1, dense: every stage split into two waves)
         assert gpu_ctx.last_kernel_name == (pipe if len(blocks) >= 12 else "k_chain<encode>")
         assert (status == 0).all()
         for k, c in zip(ks, coded):
@@ -300,7 +300,7 @@ def test_back_to_back_launches_do_not_see_each_others_state(zpq, gpu_ctx):
     for rnd_ in range(5):
         blocks = [bytes(W.make_block(64 * rnd_ + b, 3000 + 17 * b)) for b in range(40)]
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
-        assert gpu_ctx.last_kernel_name == "k_pipe2<encode>"
+        assert gpu_ctx.last_kernel_name == "k_pipe<encode>"
         assert (status == 0).all()
         assert coded == O.encode_blocks(model.header, blocks, nthreads=4)
         if rnd_ == 2:                                       # another kernel works in pool 0 in between

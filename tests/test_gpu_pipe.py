@@ -94,7 +94,7 @@ def test_rounds_and_partial_workgroups(zpq, gpu_ctx, monkeypatch, level):
     zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, nslots * model.state_bytes + 1000)
     try:
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
-        assert gpu_ctx.last_kernel_name == ("k_pipe2<encode>" if level <= 2 else "k_pipe<encode>") and gpu_ctx.last_slots == nslots
+        assert gpu_ctx.last_kernel_name == ("k_pipe2<encode>" if level == 1 else "k_pipe<encode>") and gpu_ctx.last_slots == nslots
         assert (status == 0).all() and coded == want
     finally:
         zpq.lib().zpq_ctx_set_state_budget(gpu_ctx.h, 150 << 30)
@@ -130,7 +130,7 @@ def test_small_batches_stay_with_the_lane_per_component_encoder(zpq, gpu_ctx):
     """A component wave with only a few active lanes runs at half speed (EXPERIMENTS.md 4.4): fewer than 12 resident blocks
     are coded by zpq_chain.hip's encoder; 12 and more by the pipeline, regrouped evenly over its workgroups."""
     model = zpq.Model(level=2)
-    for n, name in ((1, "k_chain<encode>"), (11, "k_chain<encode>"), (12, "k_pipe2<encode>"), (37, "k_pipe2<encode>")):
+    for n, name in ((1, "k_chain<encode>"), (11, "k_chain<encode>"), (12, "k_pipe<encode>"), (37, "k_pipe<encode>")):
         blocks = [bytes(W.make_block(b, 700 + 13 * b)) for b in range(n)]
         coded, status, _ = gpu_ctx.encode_blocks(model, blocks)
         assert gpu_ctx.last_kernel_name == name and (status == 0).all()
@@ -215,9 +215,9 @@ def test_blocks_larger_than_64k(zpq, gpu_ctx, monkeypatch, level):
 
 
 def test_split_stage_encoder_orders_and_rejected_orders(zpq, gpu_ctx, monkeypatch):
-    """Levels 1 and 2 run k_pipe2 by default (level 1: every stage split into a history and a weights wave; level 2, round 4: the
-    same with both ISSEs PAIRED on the halves of one wave, roles c = H1+H2 and d = P1+P2); ZPQ_ENC_SPLIT=0 puts them back on
-    k_pipe; another complete wave order is taken; an order that names a component the model does not have, leaves out the
+    """Level 1 runs k_pipe2 (every stage split into a history and a weights wave) by default; ZPQ_ENC_SPLIT=0 puts it back on
+    k_pipe; level 2 takes k_pipe2 on request, also with both ISSEs PAIRED on the halves of one wave (round 4: roles c = H1+H2 and
+    d = P1+P2); another complete wave order is taken; an order that names a component the model does not have, leaves out the
     coder, or names a stage twice is IGNORED (it used to be launched as given).  Same coded bytes every time."""
     rnd = random.Random(4711)
     for level, orders in ((1, (None, "0", "60231", "6823", "6019", "02316", "6089", "64523", "0123", "60011", "602316", "60c31", "6d02")),
@@ -226,7 +226,7 @@ def test_split_stage_encoder_orders_and_rejected_orders(zpq, gpu_ctx, monkeypatc
         model = zpq.Model(level=level)
         blocks = mixed_blocks(rnd, 40, [0, 1, 300, 1200, 2048])
         want = O.encode_blocks(model.header, blocks, nthreads=4)
-        default = "k_pipe2<encode>"
+        default = "k_pipe2<encode>" if level == 1 else "k_pipe<encode>"
         for order in orders:
             if order is None:
                 monkeypatch.delenv("ZPQ_ENC_SPLIT", raising=False)

@@ -547,12 +547,16 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
     u32 prev = 0, m4 = 0, b4 = 0;
     u32 slotn = 1;
     u32 ch = 0;
+#ifdef ZPP_DEBUG_NO_ROWS   // timing experiment only (wrong output): no hash-row traffic
+#define ZPH_LOAD_ROWS(q_, po_) do { q_.A = u32x4{(po_), 0, 0, 0}; q_.B = q_.A; q_.C = q_.A; } while (0)
+#else
 #define ZPH_LOAD_ROWS(q_, po_)                                                          \
     do {                                                                                \
         q_.A = *reinterpret_cast<const u32x4 *>(tbase + (po_));                         \
         q_.B = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 16u));                 \
         q_.C = *reinterpret_cast<const u32x4 *>(tbase + ((po_) ^ 32u));                 \
     } while (0)
+#endif
     auto request = [&](const u32 hc, const u32 c8v) -> Req {
         Req q;
         const u32 cx = hc + 16u * c8v;
@@ -588,7 +592,9 @@ __device__ __forceinline__ void hist_loop(const StageArgs &S, const int delay)
         R.x = hit ? Rx : chk; R.y = hit ? Ry : 0u; R.z = hit ? Rz : 0u; R.w = hit ? Rw : 0u;
         u32 poff2 = L1.off;
         asm volatile("; order: row store after the prefetched rows are consumed" : "+v"(poff2) : "v"(R.x), "v"(R.w));
+#ifndef ZPP_DEBUG_NO_ROWS
         if (have1) *reinterpret_cast<u32x4 *>(tbase + poff2) = u32x4{L1.x, L1.y, L1.z, L1.w};
+#endif
         return R;
     };
     auto run_vm = [&](const u32 byte) -> u32 {         // comp_loop
@@ -1307,8 +1313,11 @@ extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, in
         const char *ev = getenv("ZPQ_ENC_SPLIT");
         cfg.split_enc = 0;
         if (!cfg.sparse && !cfg.has_mix2 && (cfg.nch_spec == 2 || cfg.nch_spec == 3) && !(ev && atoi(ev) == 0 && strlen(ev) == 1)) {
-            // (level 2, round 4: both ISSEs on the two halves of one wave, "60cd1": five roles, coder + ICM counters on one SIMD as at level 1)
-            const char *order = cfg.nch_spec == 2 ? "60231" : (blocks_per_wg <= 32 ? "60cd1" : nullptr);
+            // (level 2, round 4: both ISSEs on the two halves of one wave, "60cd1" -- five roles as at level 1 -- takes the floor
+            //  without row traffic from 113.7 to 84.8 ms, but with the rows it runs at the memory system's rate for random lines
+            //  read and written back: 119.4 / 123.7-133 / 126.3 ms against 122.7 / 121-131 / 123.7 for k_pipe on three boxes.
+            //  Opt-in: ZPQ_ENC_SPLIT=60cd1; EXPERIMENTS.md R4.10)
+            const char *order = cfg.nch_spec == 2 ? "60231" : nullptr;
             if (ev && strlen(ev) >= 4) {
                 const bool has_pair = strchr(ev, 'c') || strchr(ev, 'd');   // (a paired wave holds 2 x 32 blocks at most)
                 if (split_order_valid(ev, cfg.nch_spec) && !(has_pair && blocks_per_wg > 32)) order = ev;
