@@ -7,8 +7,11 @@ import workload as W
 ap=argparse.ArgumentParser(); ap.add_argument('--blocks',type=int,default=256); ap.add_argument('--level',type=int,default=2)
 ap.add_argument('--size',type=int,default=65536); ap.add_argument('--reps',type=int,default=2); ap.add_argument('--generic',action='store_true')
 ap.add_argument('--check',type=int,default=4); ap.add_argument('--cls',type=int,default=-1)
+ap.add_argument('--hold',type=float,default=0.0,help='GiB of device memory allocated (and kept) BEFORE the context: shifts where the slot pool lands')
 a=ap.parse_args()
-z=ge.load(); ctx=z.Context(0); model=z.Model(level=a.level)
+z=ge.load()
+hold=torch.empty(int(a.hold*(1<<30)),dtype=torch.uint8,device='cuda:0') if a.hold>0 else None
+ctx=z.Context(0); model=z.Model(level=a.level)
 nb=a.blocks; size=a.size
 arr=W.make_blocks_fast(nb,size)
 if a.cls>=0:

@@ -590,7 +590,10 @@ __global__ void __launch_bounds__(64 * MAXW) k_chain(const DBatch B, const Cfg c
         // the HBM round trip (~2000 cycles under this load, tools/micro/rowlat.hip) then hides completely instead of by half.
         // Four lines per table and byte instead of two, but four NEIGHBOURING ones: asking two steps early for four lines 256
         // bytes apart was measured slower in round 2 (321 vs 267 ms).
-#ifdef ZPQ_NO_HYP4
+        // Round 4 (EXPERIMENTS.md R4.11): on the dieted kernel the early request buys nothing any more -- level 2 x 8192, processes
+        // balanced over a box's fast and slow places: 235.3-236.9 ms without against 235.7-239.4 with -- and it reads a third more
+        // lines (4 instead of 2 per table for a byte's second nibble).  Off by default; -DZPQ_HYP4 (tools/variant.sh) brings it back.
+#ifndef ZPQ_HYP4
         constexpr bool HYP4 = false;
 #else
 #ifdef ZPQ_HYP4_L1
