@@ -180,3 +180,22 @@ def test_which_general_models_the_wave_pipeline_encodes(zpq, monkeypatch):
     assert L.zpq_gdec_applies(zpq.Model(header=C4B).h) == 1
     monkeypatch.setenv("ZPQ_DEC_GPIPE", "0")
     assert L.zpq_gdec_applies(zpq.Model(header=C4B).h) == 0
+
+
+def test_encoder_wave_orders_host_logic(zpq):
+    """ZPQ_ENC_SPLIT's wave order is checked on the host before anything is launched (zpq_pipe_split_order_valid, internal): every
+    component exactly once -- whole (8 + c), as its history / weights pair (2c, 2c + 1), or, for a three-component chain, both ISSEs
+    PAIRED on the halves of one wave (c = H1+H2, d = P1+P2) -- and exactly one coder (6)."""
+    L = zpq.lib()
+    L.zpq_pipe_split_order_valid.argtypes = [C.c_char_p, C.c_int]
+    L.zpq_pipe_split_order_valid.restype = C.c_int
+    ok = lambda o, n: L.zpq_pipe_split_order_valid(o.encode(), n)
+    for o in ("60231", "6823", "6019", "02316", "689"):
+        assert ok(o, 2) == 1, o
+    for o in ("6089", "64523", "0123", "60011", "602316", "60c31", "6d02", "60cd1", "", "6", "7089", "x"):
+        assert ok(o, 2) == 0, o
+    for o in ("6024135", "689a", "682345", "60cd1", "c6d8", "60c351", "6024d1", "86cd", "6cd01"):
+        assert ok(o, 3) == 1, o
+    for o in ("60231", "6024137", "6802345", "60cd", "60cd12", "6ccd1", "60cd13", "60cd15", "6c2d01", "60cdd1", "cd01"):
+        assert ok(o, 3) == 0, o
+    assert ok("60231", 0) == 0 and ok("60231", 4) == 0

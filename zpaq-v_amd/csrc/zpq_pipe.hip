@@ -1282,6 +1282,9 @@ static bool split_order_valid(const char *order, int nch)
     return true;
 }
 
+// (internal, for the CPU tests: is `order` a complete wave order for a chain of nch components?)
+extern "C" int zpq_pipe_split_order_valid(const char *order, int nch) { return order && nch >= 1 && nch <= 3 && split_order_valid(order, nch) ? 1 : 0; }
+
 extern "C" int zpq_launch_pipe(const DBatch *B, const DModel *hostM, int nwg, int blocks_per_wg, hipStream_t stream, const char **name_out)
 {
     if (name_out) *name_out = "k_pipe<encode>";
